@@ -1,0 +1,200 @@
+/*
+ * simclusters_ann.h -- C ABI of the MI355X-native SimClusters-ANN engine.
+ *
+ * This is the drop-in boundary for the `approximateCosineSimilarity` operator seam of
+ * sagspot/the-algorithm (all paths relative to /root/reference/):
+ *
+ *   trait ApproximateCosineSimilarity.apply
+ *     simclusters-ann/server/src/main/scala/com/twitter/simclustersann/candidate_source/ApproximateCosineSimilarity.scala:26-36
+ *   selected by flag `approximate_cosine_similarity`
+ *     simclusters-ann/server/src/main/scala/com/twitter/simclustersann/modules/SimClustersANNCandidateSourceModule.scala:19-38
+ *   called from SimClustersANNCandidateSource.fetchCandidates
+ *     simclusters-ann/server/src/main/scala/com/twitter/simclustersann/candidate_source/SimClustersANNCandidateSource.scala:66-95
+ *
+ * The reference has no FFI on this path; the only JNI precedent is swig-faiss
+ * (ann/src/main/java/com/twitter/ann/faiss/swig/swigfaissJNI.java:13-23,269): an opaque native
+ * handle (`long swigCPtr`) plus calls that take primitive arrays.  This header follows that
+ * shape: opaque handles, plain pointers and sizes, int status codes, caller-owned buffers.
+ * INTEGRATION.md shows the JNI stub and the 4th `ApproximateCosineSimilarity` object that a
+ * maintainer would add on the Scala side.
+ *
+ * Threading: an index handle is immutable after build and may be shared by any number of
+ * threads.  A batch handle is owned by one thread at a time.  No function throws or aborts;
+ * every function returns a status and sets a thread-local message (sann_last_error).
+ */
+#ifndef SIMCLUSTERS_ANN_H
+#define SIMCLUSTERS_ANN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SANN_OK 0
+#define SANN_EINVAL 1    /* bad argument */
+#define SANN_EDEVICE 2   /* HIP runtime error (message carries hipGetErrorString) */
+#define SANN_ENOMEM 3
+#define SANN_ELIMIT 4    /* a size exceeds what this build supports (message says which) */
+#define SANN_EINTERNAL 5
+
+/* ScoringAlgorithm, simclusters-ann/thrift/src/main/thrift/simClustersAnn.thrift:32-37 */
+#define SANN_ALG_DOT_PRODUCT 1
+#define SANN_ALG_COSINE 2
+#define SANN_ALG_LOG_COSINE 3
+#define SANN_ALG_COSINE_NO_SOURCE_NORM 4
+
+/* Which reference implementation's edge-case behaviour to reproduce (they agree on every
+ * input that SimClustersANNCandidateSource can produce):
+ *   ORIGINAL     ApproximateCosineSimilarity.scala:57-128   (no source-tweet exclusion unless the
+ *                source id is a tweet id; skips clusters the embedding does not contain)
+ *   OPTIMIZED    OptimizedApproximateCosineSimilarity.scala:37-111 (excludes tweet id 0 when the
+ *                source is not a tweet, :56)
+ *   EXPERIMENTAL ExperimentalApproximateCosineSimilarity.scala:41-130 (no `contains` guard: a
+ *                scanned cluster missing from the embedding has weight 0.0, :62-63) */
+#define SANN_VARIANT_ORIGINAL 0
+#define SANN_VARIANT_OPTIMIZED 1
+#define SANN_VARIANT_EXPERIMENTAL 2
+
+/* SimClustersANNConfig, simClustersAnn.thrift:18-27 -- field for field. */
+typedef struct sann_config {
+  int32_t max_num_results;               /* 1: maxNumResults (hard cap 1000, ApproximateCosineSimilarity.scala:41) */
+  int32_t candidate_embedding_type;      /* 3: candidateEmbeddingType (carried; not used by the arithmetic) */
+  double min_score;                      /* 2: minScore */
+  int32_t max_top_tweets_per_cluster;    /* 4 */
+  int32_t max_scan_clusters;             /* 5 */
+  int32_t max_tweet_candidate_age_hours; /* 6: >= 175200 disables the lower bound (:42,:67-68) */
+  int32_t min_tweet_candidate_age_hours; /* 7 */
+  int32_t ann_algorithm;                 /* 8: SANN_ALG_* */
+  int32_t reserved;
+} sann_config_t;
+
+typedef struct sann_index sann_index_t;
+typedef struct sann_batch sann_batch_t;
+
+typedef struct sann_index_options {
+  int32_t device;       /* HIP device ordinal */
+  int32_t n_partitions; /* tweet-hash partitions per cluster list inside this shard; power of two, 0 = default */
+  int32_t shard_id;     /* this shard, 0 <= shard_id < n_shards */
+  int32_t n_shards;     /* tweet-hash shards (one per GPU); 1 = whole corpus on this GPU */
+} sann_index_options_t;
+
+typedef struct sann_index_info {
+  int64_t n_clusters;      /* cluster lists held (including empty ones) */
+  int64_t n_postings;      /* postings held by this shard */
+  int64_t n_postings_total;/* postings in the lists as given (all shards) */
+  int64_t device_bytes;
+  int32_t n_partitions, shard_id, n_shards, max_list_len;
+} sann_index_info_t;
+
+/* Per-batch counters, the native side of `candidateScoresStat` and the server's StatsReceiver
+ * (ApproximateCosineSimilarity.scala:32,102). */
+typedef struct sann_batch_stats {
+  int64_t postings_scanned;  /* sum over queries of sum_c min(len_c, M) within this shard */
+  int64_t algorithmic_bytes; /* P_q*16 + n*12 + k_out*16 summed over queries */
+  int32_t n_units;           /* (query, partition) work units launched */
+  int32_t n_fallback_units;  /* units re-run on the general (global-memory) path */
+  int32_t n_requeried;       /* queries whose first-pass top-k could not be proven exact */
+  int32_t reserved;
+} sann_batch_stats_t;
+
+const char *sann_last_error(void);
+/* Library self-description, e.g. "simclusters_amd 0.1 gfx950". */
+const char *sann_version(void);
+
+/*
+ * Build a device-resident cluster -> top tweets index from posting lists as the reference's
+ * ReadableStore[ClusterId, Seq[(TweetId, Double)]] returns them
+ * (simclusters-ann/.../modules/ClusterTweetIndexProviderModule.scala:34-94 over
+ *  src/scala/com/twitter/simclusters_v2/summingbird/stores/TopKTweetsForClusterReadableStore.scala:211-229):
+ * each list already filtered to score > 0, sorted by score descending and capped.  The order
+ * inside a list is kept as given (position i is the `i` of ApproximateCosineSimilarity.scala:87).
+ * Tweet ids must be unique inside one list (they are keys of a Map in the store).
+ *   cluster_ids[n_lists]      ascending, unique
+ *   list_offsets[n_lists + 1] CSR offsets into tweet_ids / scores
+ */
+int sann_index_build(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
+                     const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores,
+                     sann_index_t **out);
+int sann_index_info(const sann_index_t *index, sann_index_info_t *info);
+/* Copy one cluster's postings held by this shard back to the host, in list order
+ * (cap = capacity of the out arrays; *n receives the number held).  Test / audit hook. */
+int sann_index_get_list(const sann_index_t *index, int32_t cluster_id, int64_t cap, int64_t *tweet_ids,
+                        double *scores, int32_t *ranks, int64_t *n);
+int sann_index_destroy(sann_index_t *index);
+
+/*
+ * Prepare a batch of nq getTweetCandidates queries against `index`.
+ *
+ *   emb_offsets[nq+1], emb_cluster_ids, emb_scores
+ *       the source SimClustersEmbedding of each query as (clusterId, score) pairs in any order;
+ *       the SimClustersEmbedding constructor semantics are applied (drop score <= 0, order by
+ *       score desc then cluster id asc; SimClustersEmbedding.scala:490-509).
+ *   source_tweet_ids[nq], has_source_tweet[nq]   (both may be NULL = no query has a tweet source)
+ *       InternalId.TweetId of sourceEmbeddingId, ApproximateCosineSimilarity.scala:48-55,90.
+ *   configs[n_configs]  n_configs is 1 (shared) or nq.
+ *   scan_offsets[nq+1], scan_cluster_ids   (both may be NULL)
+ *       the keys of clusterTweetsMap in the iteration order the caller wants the accumulation
+ *       to follow.  NULL reproduces SimClustersANNCandidateSource.fetchCandidates:
+ *       sourceEmbedding.truncate(maxScanClusters).getClusterIds().toSet, iterated in ascending
+ *       cluster id (the reference's order is JVM hash order).
+ *   now_ms  the value of Time.now (ApproximateCosineSimilarity.scala:65).
+ */
+int sann_batch_create(sann_index_t *index, int32_t variant, int64_t now_ms, int32_t nq,
+                      const int64_t *emb_offsets, const int32_t *emb_cluster_ids, const double *emb_scores,
+                      const int64_t *source_tweet_ids, const uint8_t *has_source_tweet,
+                      const sann_config_t *configs, int32_t n_configs, const int64_t *scan_offsets,
+                      const int32_t *scan_cluster_ids, sann_batch_t **out);
+/* Enqueue the batch on `hip_stream` (a hipStream_t, NULL = the null stream). Asynchronous;
+ * may be called repeatedly (results are overwritten). */
+int sann_batch_run(sann_batch_t *batch, void *hip_stream);
+/* Wait for the batch, re-running on the general path whatever the fast path flagged. After
+ * this returns SANN_OK the device results are final and exact. */
+int sann_batch_finish(sann_batch_t *batch, void *hip_stream);
+/* Copy results to the host.  Row q holds out_counts[q] (tweetId, score) pairs sorted by score
+ * descending (ties: tweet id ascending) at out_ids + q*out_stride; out_map_sizes[q] is
+ * candidateScoresMap.size.  out_stride >= min(max over queries of maxNumResults, 1000). */
+int sann_batch_results(sann_batch_t *batch, int64_t *out_ids, double *out_scores, int32_t out_stride,
+                       int32_t *out_counts, int32_t *out_map_sizes);
+/* Device pointers of the same results (row stride *stride entries), for an on-device merge
+ * across shards: d_ids int64[nq*stride], d_scores double[nq*stride], d_counts int32[nq],
+ * d_map_sizes int32[nq]. */
+int sann_batch_device_results(sann_batch_t *batch, void **d_ids, void **d_scores, void **d_counts,
+                              void **d_map_sizes, int32_t *stride);
+int sann_batch_stats(sann_batch_t *batch, sann_batch_stats_t *stats);
+int sann_batch_destroy(sann_batch_t *batch);
+
+/* One call = create + run + finish + results + destroy: the shape a JNI stub binds. */
+int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_ms, int32_t nq,
+                              const int64_t *emb_offsets, const int32_t *emb_cluster_ids,
+                              const double *emb_scores, const int64_t *source_tweet_ids,
+                              const uint8_t *has_source_tweet, const sann_config_t *configs,
+                              int32_t n_configs, const int64_t *scan_offsets, const int32_t *scan_cluster_ids,
+                              int64_t *out_ids, double *out_scores, int32_t out_stride, int32_t *out_counts,
+                              int32_t *out_map_sizes);
+
+/*
+ * Merge per-shard results on the device: the `ComposedQueryable` pattern
+ * (ann/src/main/scala/com/twitter/ann/common/ShardApi.scala:71-87) applied to tweet-hash
+ * shards, where it is exact because every tweet's postings live in one shard.
+ * Inputs are the all-gathered device buffers, shard-major: d_ids[n_shards][nq][stride] ...
+ * Output rows have stride `stride`; d_out_map_sizes is the sum over shards.
+ */
+int sann_merge_shards(int32_t device, void *hip_stream, int32_t n_shards, int32_t nq, int32_t stride,
+                      const void *d_ids, const void *d_scores, const void *d_counts, const void *d_map_sizes,
+                      const void *d_k /* int32[nq]: min(maxNumResults,1000) per query */, void *d_out_ids,
+                      void *d_out_scores, void *d_out_counts, void *d_out_map_sizes);
+
+/* Device pointer to int32[nq] holding min(max(maxNumResults,0),1000) per query. */
+int sann_batch_device_k(sann_batch_t *batch, void **d_k);
+
+/* Audit hook: out[i] = the normalisation of ApproximateCosineSimilarity.scala:111-119 evaluated on
+ * the device for (dot[i], nsq[i]); host arrays in and out.  Lets a test compare the device's
+ * fp64 division / sqrt / log with the host bit for bit. */
+int sann_debug_normalise(int32_t device, int32_t alg, int32_t n, const double *dot, const double *nsq, double l2norm,
+                         double lognorm, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,138 @@
+"""ctypes loader of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY: imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "liboracle.so")
+
+
+class oracle_sann_config(C.Structure):
+    _fields_ = [
+        ("max_num_results", C.c_int32),
+        ("min_score", C.c_double),
+        ("candidate_embedding_type", C.c_int32),
+        ("max_top_tweets_per_cluster", C.c_int32),
+        ("max_scan_clusters", C.c_int32),
+        ("max_tweet_candidate_age_hours", C.c_int32),
+        ("min_tweet_candidate_age_hours", C.c_int32),
+        ("ann_algorithm", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        src_newer = (not os.path.exists(LIB)) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(LIB)
+            for f in ("simclusters_oracle.c", "oracle_baseline.c", "Makefile"))
+        if src_newer:
+            build()
+        L = C.CDLL(LIB)
+        L.oracle_strict_log.restype = C.c_double
+        L.oracle_strict_log.argtypes = [C.c_double]
+        L.oracle_snowflake_first_id_for.restype = C.c_int64
+        L.oracle_snowflake_first_id_for.argtypes = [C.c_int64]
+        L.oracle_pair_score.restype = C.c_double
+        L.oracle_pair_score.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.oracle_sann_query.restype = C.c_int32
+        L.oracle_sann_query.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                        C.POINTER(oracle_sann_config), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_int32)]
+        L.oracle_embedding_build.restype = C.c_void_p
+        L.oracle_embedding_build.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+        L.oracle_embedding_free.argtypes = [C.c_void_p]
+        L.oracle_embedding_size.restype = C.c_int32
+        L.oracle_embedding_size.argtypes = [C.c_void_p]
+        L.oracle_embedding_export.argtypes = [C.c_void_p] * 5
+        for f in ("oracle_embedding_l2norm", "oracle_embedding_lognorm", "oracle_embedding_expscalednorm"):
+            getattr(L, f).restype = C.c_double
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.oracle_baseline_run.restype = C.c_double
+        L.oracle_baseline_run.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(oracle_sann_config), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_config(cfg) -> oracle_sann_config:
+    """cfg: any object with the SimClustersANNConfig thrift field names."""
+    return oracle_sann_config(int(cfg.maxNumResults), float(cfg.minScore), int(cfg.candidateEmbeddingType),
+                              int(cfg.maxTopTweetsPerCluster), int(cfg.maxScanClusters),
+                              int(cfg.maxTweetCandidateAgeHours), int(cfg.minTweetCandidateAgeHours),
+                              int(cfg.annAlgorithm))
+
+
+def sann_query(emb_ids, emb_scores, source_tweet_id, cfg, now_ms, cluster_ids, list_offsets, tweet_ids, scores,
+               variant=0, scan_order=None):
+    """Returns (ids int64[n], scores float64[n], map_size)."""
+    L = lib()
+    emb_ids = np.ascontiguousarray(emb_ids, np.int32)
+    emb_scores = np.ascontiguousarray(emb_scores, np.float64)
+    cluster_ids = np.ascontiguousarray(cluster_ids, np.int32)
+    list_offsets = np.ascontiguousarray(list_offsets, np.int64)
+    tweet_ids = np.ascontiguousarray(tweet_ids, np.int64)
+    scores = np.ascontiguousarray(scores, np.float64)
+    so = None if scan_order is None else np.ascontiguousarray(scan_order, np.int32)
+    out_ids = np.zeros(1000, np.int64)
+    out_scores = np.zeros(1000, np.float64)
+    msz = C.c_int32()
+    c = make_config(cfg)
+    n = L.oracle_sann_query(int(variant), len(emb_ids), _p(emb_ids), _p(emb_scores),
+                            0 if source_tweet_id is None else 1, 0 if source_tweet_id is None else int(source_tweet_id),
+                            C.byref(c), int(now_ms), len(cluster_ids), _p(cluster_ids), _p(list_offsets), _p(tweet_ids),
+                            _p(scores), 0 if so is None else len(so), _p(so), _p(out_ids), _p(out_scores), C.byref(msz))
+    return out_ids[:n].copy(), out_scores[:n].copy(), msz.value
+
+
+def pair_score(algorithm, ids1, sc1, ids2, sc2) -> float:
+    a = np.ascontiguousarray(ids1, np.int32)
+    b = np.ascontiguousarray(sc1, np.float64)
+    c = np.ascontiguousarray(ids2, np.int32)
+    d = np.ascontiguousarray(sc2, np.float64)
+    return lib().oracle_pair_score(int(algorithm), len(a), _p(a), _p(b), len(c), _p(c), _p(d))
+
+
+def embedding(ids, scores, truncate=-1):
+    """Returns dict with clusterIds/scores (desc) and sortedClusterIds/sortedScores (asc id), norms."""
+    L = lib()
+    a = np.ascontiguousarray(ids, np.int32)
+    b = np.ascontiguousarray(scores, np.float64)
+    e = L.oracle_embedding_build(len(a), _p(a), _p(b), int(truncate))
+    try:
+        n = L.oracle_embedding_size(e)
+        ci = np.zeros(n, np.int32); cs = np.zeros(n); si = np.zeros(n, np.int32); ss = np.zeros(n)
+        L.oracle_embedding_export(e, _p(ci), _p(cs), _p(si), _p(ss))
+        return dict(clusterIds=ci, scores=cs, sortedClusterIds=si, sortedScores=ss,
+                    l2norm=L.oracle_embedding_l2norm(e), logNorm=L.oracle_embedding_lognorm(e),
+                    expScaledNorm=L.oracle_embedding_expscalednorm(e))
+    finally:
+        L.oracle_embedding_free(e)
+
+
+def baseline_run(variant, n_threads, emb_offsets, emb_ids, emb_scores, cfg, now_ms, cluster_ids, list_offsets,
+                 tweet_ids, scores, out_ids, out_scores, out_counts) -> float:
+    """Run every query through the restated Scala path on n_threads threads; returns seconds."""
+    c = make_config(cfg)
+    nq = len(emb_offsets) - 1
+    return lib().oracle_baseline_run(int(variant), int(n_threads), nq, _p(emb_offsets), _p(emb_ids), _p(emb_scores),
+                                     C.byref(c), int(now_ms), len(cluster_ids), _p(cluster_ids), _p(list_offsets),
+                                     _p(tweet_ids), _p(scores), _p(out_ids), _p(out_scores), _p(out_counts))

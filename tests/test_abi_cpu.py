@@ -1,0 +1,46 @@
+"""The C-ABI library loads on a box without a GPU and exports every symbol the header declares.
+No compute calls here (argument validation only, which returns before any HIP call)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load_library()
+    header = open(os.path.join(ROOT, "include", "simclusters_ann.h")).read()
+    declared = set(re.findall(r"\b(sann_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/simclusters_ann.h but not exported"
+    # the Python binding covers the whole header too
+    assert declared == set(pkg.simclusters_ann.exported_symbols())
+
+
+def test_version_and_error_paths(pkg):
+    lib = pkg.load_library()
+    assert b"gfx950" in lib.sann_version()
+    h = C.c_void_p()
+    assert lib.sann_index_build(None, 0, None, None, None, None, C.byref(h)) == 1  # SANN_EINVAL
+    assert b"opts" in lib.sann_last_error()
+    opts = pkg.simclusters_ann.sann_index_options_t(0, 3, 0, 1)  # 3 partitions: not a power of two
+    assert lib.sann_index_build(C.byref(opts), 0, None, None, None, None, C.byref(h)) == 1
+    assert lib.sann_batch_run(None, None) == 1
+    assert lib.sann_batch_destroy(None) == 0
+    assert lib.sann_index_destroy(None) == 0
+
+
+def test_config_struct_layout_matches_header(pkg):
+    # 4+4+8+5*4+4 = 40 bytes, min_score at offset 8
+    c = pkg.simclusters_ann.sann_config_t
+    assert C.sizeof(c) == 40
+    assert c.min_score.offset == 8
+    assert c.ann_algorithm.offset == 32
+
+
+def test_missing_library_fails_loudly(pkg, tmp_path):
+    with pytest.raises(FileNotFoundError):
+        pkg.load_library(str(tmp_path / "nope.so"))

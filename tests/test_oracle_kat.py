@@ -1,0 +1,87 @@
+"""The CPU oracle against the hand-derived golden vectors (tests/golden/sann_kat.json).
+No GPU.  These pin the oracle before anything is compared with it."""
+import json
+import math
+import os
+import struct
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "sann_kat.json")))
+
+
+class Cfg:
+    def __init__(self, d):
+        self.__dict__.update(d)
+
+
+def lists_to_csr(lists):
+    cids = sorted(int(c) for c in lists)
+    offs, tids, scs = [0], [], []
+    for c in cids:
+        for t, s in lists[str(c)]:
+            tids.append(t)
+            scs.append(s)
+        offs.append(len(tids))
+    return (np.array(cids, np.int32), np.array(offs, np.int64), np.array(tids, np.int64), np.array(scs, np.float64))
+
+
+def ulps(a, b):
+    if a == b:
+        return 0
+    ia = struct.unpack("<q", struct.pack("<d", a))[0]
+    ib = struct.unpack("<q", struct.pack("<d", b))[0]
+    return abs(ia - ib)
+
+
+@pytest.mark.parametrize("case", KAT["sann"], ids=[c["name"] for c in KAT["sann"]])
+def test_sann_kat(oracle, case):
+    cids, offs, tids, scs = lists_to_csr(case["lists"])
+    emb = case["emb"]
+    ids, scores, msz = oracle.sann_query([e[0] for e in emb], [e[1] for e in emb], case["source"], Cfg(case["config"]),
+                                         case["now_ms"], cids, offs, tids, scs, variant=case["variant"],
+                                         scan_order=case.get("scan_keys"))
+    exp = case["expect"]
+    assert msz == case["map_size"]
+    assert [int(i) for i in ids] == [e[0] for e in exp]
+    for got, e in zip(scores, exp):
+        assert ulps(float(got), float.fromhex(e[1])) <= case["ulp"], (got, float.fromhex(e[1]))
+
+
+@pytest.mark.parametrize("case", KAT["pairs"], ids=[c["name"] for c in KAT["pairs"]])
+def test_pair_kat(oracle, case):
+    got = oracle.pair_score(case["alg"], [x[0] for x in case["a"]], [x[1] for x in case["a"]],
+                            [x[0] for x in case["b"]], [x[1] for x in case["b"]])
+    assert ulps(got, float.fromhex(case["expect"])) <= case["ulp"]
+
+
+def test_snowflake(oracle):
+    for s in KAT["snowflake"]:
+        assert oracle.lib().oracle_snowflake_first_id_for(s["ms"]) == s["id"]
+    # layout pinned in-repo: ms = 1288834974657 + (id >> 22)  (BQGenerationUtil.scala:150-153)
+    i = oracle.lib().oracle_snowflake_first_id_for(1_700_000_000_000)
+    assert 1288834974657 + (i >> 22) == 1_700_000_000_000
+
+
+def test_strict_log_within_one_ulp_of_libm(oracle):
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([np.exp(rng.normal(0, 4, 20000)), 1 + rng.uniform(-1e-7, 1e-7, 5000), [1.0, 2.0, 26.0, 1e-320]])
+    L = oracle.lib()
+    for x in xs:
+        assert ulps(L.oracle_strict_log(float(x)), math.log(float(x))) <= 1
+    assert L.oracle_strict_log(1.0) == 0.0
+    assert L.oracle_strict_log(0.0) == -math.inf
+    assert math.isnan(L.oracle_strict_log(-1.0))
+
+
+def test_embedding_constructor(oracle):
+    # SimClustersEmbedding.scala:490-509: drop <= 0, sort (score desc, id asc); sorted arrays by id
+    e = oracle.embedding([7, 3, 9, 1, 5], [2.0, 5.0, 2.0, -1.0, 0.0])
+    assert list(e["clusterIds"]) == [3, 7, 9]
+    assert list(e["scores"]) == [5.0, 2.0, 2.0]
+    assert list(e["sortedClusterIds"]) == [3, 7, 9]
+    assert e["l2norm"] == math.sqrt(5.0 * 5.0 + 2.0 * 2.0 + 2.0 * 2.0)
+    t = oracle.embedding([7, 3, 9], [2.0, 5.0, 2.0], truncate=2)
+    assert list(t["clusterIds"]) == [3, 7]

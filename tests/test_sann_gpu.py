@@ -1,0 +1,280 @@
+"""GPU parity: the HIP path through the C ABI against the CPU oracle on the same inputs.
+Bar: tweet ids bit-exact (same set, same order), scores bit-exact (fp64; no tolerance needed
+because both sides do unfused IEEE arithmetic in the same order), candidateScoresMap.size equal."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "sann_kat.json")))
+
+
+class Cfg:
+    def __init__(self, d):
+        self.__dict__.update(d)
+
+
+def lists_to_csr(lists):
+    cids = sorted(int(c) for c in lists)
+    offs, tids, scs = [0], [], []
+    for c in cids:
+        for t, s in lists[str(c)]:
+            tids.append(t)
+            scs.append(s)
+        offs.append(len(tids))
+    return (np.array(cids, np.int32), np.array(offs, np.int64), np.array(tids, np.int64), np.array(scs, np.float64))
+
+
+@pytest.mark.parametrize("P", [1, 4, 32])
+@pytest.mark.parametrize("case", KAT["sann"], ids=[c["name"] for c in KAT["sann"]])
+def test_kat_through_c_abi(pkg, case, P):
+    cids, offs, tids, scs = lists_to_csr(case["lists"])
+    index = pkg.ClusterTweetIndex(cids, offs, tids, scs, n_partitions=P)
+    c = case["config"]
+    cfg = pkg.SimClustersANNConfig(**{**c, "annAlgorithm": pkg.ScoringAlgorithm(c["annAlgorithm"])})
+    op = pkg.ApproximateCosineSimilarity(index, pkg.Variant(case["variant"]), now_ms=case["now_ms"])
+    seen = []
+    got = op.apply([(e[0], e[1]) for e in case["emb"]], case["source"], cfg, seen.append, case.get("scan_keys"))
+    assert seen == [case["map_size"]]
+    assert [g[0] for g in got] == [e[0] for e in case["expect"]]
+    for g, e in zip(got, case["expect"]):
+        exp = float.fromhex(e[1])
+        if case["ulp"] == 0:
+            assert g[1] == exp
+        else:
+            assert abs(g[1] - exp) <= case["ulp"] * math.ulp(exp)
+    index.close()
+
+
+def run_batch(pkg, index, co, offs, cids, scs, cfg, variant=0, **kw):
+    qb = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=co.now_ms, variant=pkg.Variant(variant), **kw)
+    qb.run()
+    qb.finish()
+    out = qb.results()
+    st = qb.stats()
+    qb.close()
+    return out, st
+
+
+def check_against_oracle(pkg, oracle, co, offs, cids, scs, cfg, out, variant=0, sources=None, scan=None):
+    ids, scores, counts, msz = out
+    nq = len(offs) - 1
+    for q in range(nq):
+        cq = cfg[q] if isinstance(cfg, list) else cfg
+        src = None if sources is None else sources[q]
+        so = None if scan is None else scan[q]
+        o_ids, o_sc, o_msz = oracle.sann_query(cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]], src, cq, co.now_ms,
+                                               co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores,
+                                               variant=variant, scan_order=so)
+        assert counts[q] == len(o_ids), (q, counts[q], len(o_ids))
+        assert msz[q] == o_msz, (q, msz[q], o_msz)
+        assert np.array_equal(ids[q, :counts[q]], o_ids), f"query {q}: id order differs"
+        assert np.array_equal(scores[q, :counts[q]].view(np.int64), o_sc.view(np.int64)), f"query {q}: scores differ"
+
+
+@pytest.fixture(scope="module")
+def small(pkg):
+    co = pkg.corpus.make_corpus(30000, 1500, seed=21, index_cap=400)
+    offs, cids, scs = pkg.corpus.make_queries(24, 1500, seed=22, clusters_per_user=50)
+    return co, offs, cids, scs
+
+
+@pytest.mark.parametrize("P", [1, 8, 32])
+@pytest.mark.parametrize("alg", [1, 2, 3, 4])
+def test_random_corpus_bit_exact(pkg, oracle, small, alg, P):
+    co, offs, cids, scs = small
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=P)
+    cfg = pkg.SimClustersANNConfig(maxNumResults=400, maxTopTweetsPerCluster=300, maxScanClusters=50,
+                                   annAlgorithm=pkg.ScoringAlgorithm(alg))
+    out, st = run_batch(pkg, index, co, offs, cids, scs, cfg)
+    check_against_oracle(pkg, oracle, co, offs, cids, scs, cfg, out)
+    assert st.postings_scanned > 0
+    index.close()
+
+
+def test_per_query_configs_sources_and_windows(pkg, oracle, small):
+    co, offs, cids, scs = small
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=16)
+    rng = np.random.default_rng(5)
+    nq = len(offs) - 1
+    cfgs, sources = [], []
+    for q in range(nq):
+        cfgs.append(pkg.SimClustersANNConfig(
+            maxNumResults=int(rng.choice([1, 10, 400, 1000, 5000])), minScore=float(rng.choice([0.0, 0.05, 0.3])),
+            maxTopTweetsPerCluster=int(rng.choice([1, 50, 400, 10000])), maxScanClusters=int(rng.choice([1, 5, 50, 200])),
+            maxTweetCandidateAgeHours=int(rng.choice([6, 12, 24, 175200])), minTweetCandidateAgeHours=int(rng.choice([0, 1, 3])),
+            annAlgorithm=pkg.ScoringAlgorithm(int(rng.integers(1, 5)))))
+        # half the queries are tweet-sourced with an id that exists in the corpus
+        sources.append(int(co.tweet_ids[rng.integers(0, len(co.tweet_ids))]) if q % 2 else None)
+    src = np.array([0 if s is None else s for s in sources], np.int64)
+    has = np.array([0 if s is None else 1 for s in sources], np.uint8)
+    for variant in (0, 1, 2):
+        out, _ = run_batch(pkg, index, co, offs, cids, scs, cfgs, variant=variant, source_tweet_ids=src,
+                           has_source_tweet=has)
+        check_against_oracle(pkg, oracle, co, offs, cids, scs, cfgs, out, variant=variant, sources=sources)
+    index.close()
+
+
+def test_heavy_duplication_and_explicit_order(pkg, oracle):
+    """Every cluster lists the SAME tweets: each candidate is a 40-term ordered fp64 sum, and the
+    explicit key order changes last-ulp results (accumulation order is the caller's)."""
+    rng = np.random.default_rng(9)
+    n_c, n_t = 40, 700
+    base = (np.arange(n_t, dtype=np.int64) * 7919 + 12345) << 22
+    lists = {}
+    for c in range(1, n_c + 1):
+        s = np.sort(np.exp(rng.normal(-2, 1, n_t)))[::-1]
+        t = rng.permutation(base)
+        lists[c] = list(zip(t.tolist(), s.tolist()))
+    index = pkg.ClusterTweetIndex.from_map(lists, n_partitions=8)
+    cids_csr = np.array(sorted(lists), np.int32)
+    offs_csr = np.arange(0, (n_c + 1) * n_t, n_t, dtype=np.int64)
+    t_csr = np.concatenate([np.array([x[0] for x in lists[c]], np.int64) for c in sorted(lists)])
+    s_csr = np.concatenate([np.array([x[1] for x in lists[c]], np.float64) for c in sorted(lists)])
+
+    class Co:
+        now_ms = 1_700_000_000_000
+        cluster_ids, list_offsets, tweet_ids, scores = cids_csr, offs_csr, t_csr, s_csr
+
+    emb_c = np.arange(1, n_c + 1, dtype=np.int32)
+    emb_s = np.exp(rng.normal(0, 1, n_c))
+    offs = np.array([0, n_c, 2 * n_c], np.int64)
+    cids = np.concatenate([emb_c, emb_c])
+    scs = np.concatenate([emb_s, emb_s])
+    order_a = list(range(1, n_c + 1))
+    order_b = list(range(n_c, 0, -1))
+    so = np.array([0, n_c, 2 * n_c], np.int64)
+    sc = np.array(order_a + order_b, np.int32)
+    for alg in (1, 2, 3):
+        cfg = pkg.SimClustersANNConfig(maxNumResults=1000, maxTopTweetsPerCluster=n_t, maxScanClusters=n_c,
+                                       maxTweetCandidateAgeHours=175200, annAlgorithm=pkg.ScoringAlgorithm(alg))
+        out, _ = run_batch(pkg, index, Co, offs, cids, scs, cfg, scan_offsets=so, scan_cluster_ids=sc)
+        check_against_oracle(pkg, oracle, Co, offs, cids, scs, cfg, out, scan=[order_a, order_b])
+        assert out[3][0] == n_t  # candidateScoresMap.size: every tweet once
+    # the two orders give different last bits for at least one candidate (so order really matters)
+    cfg = pkg.SimClustersANNConfig(maxNumResults=1000, maxTopTweetsPerCluster=n_t, maxScanClusters=n_c,
+                                   maxTweetCandidateAgeHours=175200, annAlgorithm=pkg.ScoringAlgorithm.DotProduct)
+    out, _ = run_batch(pkg, index, Co, offs, cids, scs, cfg, scan_offsets=so, scan_cluster_ids=sc)
+    a = dict(zip(out[0][0, :out[2][0]].tolist(), out[1][0, :out[2][0]].tolist()))
+    b = dict(zip(out[0][1, :out[2][1]].tolist(), out[1][1, :out[2][1]].tolist()))
+    assert any(a[t] != b[t] for t in a if t in b)
+    index.close()
+
+
+def test_edge_cases(pkg, oracle, small):
+    co, offs, cids, scs = small
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=4)
+    # empty batch
+    qb = pkg.QueryBatch(index, np.zeros(1, np.int64), np.empty(0, np.int32), np.empty(0), pkg.SimClustersANNConfig(),
+                        now_ms=co.now_ms)
+    qb.run(); qb.finish(); qb.close()
+    # empty embeddings, k = 0, negative k / M, tweet id -1 and INT64 extremes in the index
+    e_offs = np.array([0, 0, 3, 6, 9], np.int64)
+    e_c = np.array([5, 6, 7] * 3, np.int32)
+    e_s = np.array([1.0, 2.0, 3.0] * 3)
+    cfgs = [pkg.SimClustersANNConfig(), pkg.SimClustersANNConfig(maxNumResults=0),
+            pkg.SimClustersANNConfig(maxNumResults=-3), pkg.SimClustersANNConfig(maxTopTweetsPerCluster=-1)]
+    out, _ = run_batch(pkg, index, co, e_offs, e_c, e_s, cfgs)
+    check_against_oracle(pkg, oracle, co, e_offs, e_c, e_s, cfgs, out)
+    assert list(out[2]) == [0, 0, 0, 0]
+    index.close()
+
+    lists = {1: [(-1, 3.0), (2**63 - 1, 2.0), (-(2**63), 1.5), (0, 1.0)], 2: [(-1, 0.5), (7, 0.25)]}
+    ix2 = pkg.ClusterTweetIndex.from_map(lists, n_partitions=2)
+    # one second after the Snowflake epoch with a 24 h window: earliest is negative, so tweet id
+    # -1 (the hash table's sentinel value) is a legal candidate and must take the special slot
+    now = 1288834974657 + 1000
+    op = pkg.ApproximateCosineSimilarity(ix2, pkg.Variant.original, now_ms=now)
+    cfg = pkg.SimClustersANNConfig(maxTweetCandidateAgeHours=24, annAlgorithm=pkg.ScoringAlgorithm.DotProduct)
+    got = op.apply([(1, 2.0), (2, 4.0)], None, cfg)
+    cids_c = np.array([1, 2], np.int32); offs_c = np.array([0, 4, 6], np.int64)
+    t_c = np.array([-1, 2**63 - 1, -(2**63), 0, -1, 7], np.int64); s_c = np.array([3.0, 2.0, 1.5, 1.0, 0.5, 0.25])
+    o_ids, o_sc, _ = oracle.sann_query([1, 2], [2.0, 4.0], None, cfg, now, cids_c, offs_c, t_c, s_c)
+    assert [g[0] for g in got] == o_ids.tolist() and [g[1] for g in got] == o_sc.tolist()
+    assert got[0] == (-1, 3.0 * 2.0 + 0.5 * 4.0) and {t for t, _ in got} == {-1, 0, 7}
+    ix2.close()
+
+
+def test_tweet_hash_shards_merge_exactly(pkg, oracle, small):
+    """Two tweet-hash shards on one GPU + sann_merge_shards == the unsharded answer (the
+    ComposedQueryable pattern, ShardApi.scala:71-87)."""
+    import ctypes as C
+    import torch
+
+    co, offs, cids, scs = small
+    cfg = pkg.SimClustersANNConfig(maxNumResults=400, maxTopTweetsPerCluster=300)
+    nq = len(offs) - 1
+    S = 3
+    batches, bufs = [], []
+    for s in range(S):
+        ix = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=8, shard_id=s,
+                                   n_shards=S)
+        qb = pkg.QueryBatch(ix, offs, cids, scs, cfg, now_ms=co.now_ms)
+        qb.run(); qb.finish()
+        batches.append((ix, qb))
+    assert sum(b[0].info().n_postings for b in batches) == batches[0][0].info().n_postings_total
+    stride = batches[0][1].stride
+    dev = torch.device("cuda:0")
+    g_ids = torch.zeros((S, nq, stride), dtype=torch.int64, device=dev)
+    g_sc = torch.zeros((S, nq, stride), dtype=torch.float64, device=dev)
+    g_cnt = torch.zeros((S, nq), dtype=torch.int32, device=dev)
+    g_msz = torch.zeros((S, nq), dtype=torch.int32, device=dev)
+    hip = C.CDLL("libamdhip64.so")
+    for s, (ix, qb) in enumerate(batches):
+        (p_ids, p_sc, p_cnt, p_msz), st = qb.device_results()
+        assert st == stride
+        for dst, src, nbytes in ((g_ids[s], p_ids, nq * stride * 8), (g_sc[s], p_sc, nq * stride * 8),
+                                 (g_cnt[s], p_cnt, nq * 4), (g_msz[s], p_msz, nq * 4)):
+            assert hip.hipMemcpy(C.c_void_p(dst.data_ptr()), C.c_void_p(src), C.c_size_t(nbytes), 3) == 0
+    o_ids = torch.zeros((nq, stride), dtype=torch.int64, device=dev)
+    o_sc = torch.zeros((nq, stride), dtype=torch.float64, device=dev)
+    o_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+    o_msz = torch.zeros(nq, dtype=torch.int32, device=dev)
+    lib = pkg.load_library()
+    rc = lib.sann_merge_shards(0, None, S, nq, stride, g_ids.data_ptr(), g_sc.data_ptr(), g_cnt.data_ptr(),
+                               g_msz.data_ptr(), batches[0][1].device_k(), o_ids.data_ptr(), o_sc.data_ptr(),
+                               o_cnt.data_ptr(), o_msz.data_ptr())
+    assert rc == 0, lib.sann_last_error()
+    torch.cuda.synchronize()
+    out = (o_ids.cpu().numpy(), o_sc.cpu().numpy(), o_cnt.cpu().numpy(), o_msz.cpu().numpy())
+    check_against_oracle(pkg, oracle, co, offs, cids, scs, cfg, out)
+    for ix, qb in batches:
+        qb.close(); ix.close()
+
+
+def test_device_fp64_division_sqrt_log_are_bit_exact(pkg, oracle):
+    """The normalisation (ApproximateCosineSimilarity.scala:111-119) evaluated on the device equals
+    the host's IEEE result bit for bit: correctly rounded / and sqrt, and the fdlibm log."""
+    import ctypes as C
+
+    rng = np.random.default_rng(17)
+    n = 400_000
+    dot = np.exp(rng.normal(0, 3, n))
+    nsq = np.exp(rng.normal(0, 4, n))
+    nsq[:1000] = rng.uniform(1e-300, 1e-290, 1000)
+    nsq[1000:2000] = rng.uniform(1e-320, 1e-310, 1000)  # subnormal
+    l2, ln = 3.3721, 2.1234
+    lib = pkg.load_library()
+    out = np.zeros(n)
+    L = oracle.lib()
+    for alg in (1, 2, 3, 4):
+        rc = lib.sann_debug_normalise(0, alg, n, dot.ctypes.data_as(C.c_void_p), nsq.ctypes.data_as(C.c_void_p),
+                                      l2, ln, out.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        if alg == 1:
+            ref = dot
+        elif alg == 2:
+            ref = dot / l2 / np.sqrt(nsq)
+        elif alg == 4:
+            ref = dot / np.sqrt(nsq)
+        else:
+            lg = np.array([L.oracle_strict_log(float(1 + x)) for x in nsq[:50000]])
+            ref = dot[:50000] / ln / lg
+        m = len(ref)
+        bad = np.nonzero(out[:m].view(np.int64) != np.asarray(ref).view(np.int64))[0]
+        assert len(bad) == 0, (alg, len(bad), out[bad[:3]], np.asarray(ref)[bad[:3]])

@@ -1,0 +1,130 @@
+"""Synthetic SimClusters corpus and query generator, numpy, deterministic.
+
+Shapes and constants come from the reference (paths relative to /root/reference/):
+  144,428 clusters                 simclusters-ann/.../SimclustersAnnWarmupHandler.scala:33
+  ~25 clusters per tweet, cap 50   src/scala/com/twitter/simclusters_v2/summingbird/storm/TweetJob.scala:74,
+                                   .../scio/bq_generation/simclusters_index_generation/Config.scala:54
+  index cap 2000 tweets/cluster    .../simclusters_index_generation/Config.scala:58
+  50 clusters per user embedding   .../summingbird/common/Configs.scala:43
+  Snowflake id layout              .../scio/bq_generation/common/BQGenerationUtil.scala:150-153
+  posting-list materialisation     .../summingbird/stores/TopKTweetsForClusterReadableStore.scala:211-229
+                                   (filter > 0, sort by score descending, take)
+
+Cluster popularity is Zipf(s=1) realised as the log-uniform law P(rank r) = ln(1+1/r)/ln(C+1),
+r = floor((C+1)^u); ranks map to cluster ids through a fixed permutation so that hot clusters
+are spread over the id range (matters for cluster-range sharding).
+
+This generator serves tests and small benchmarks (<= a few million tweets).  The 100M-tweet
+corpus is generated on the device by the library (sann_corpus_*), following the same law.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Tuple
+
+import numpy as np
+
+N_CLUSTERS = 144_428
+NOW_MS = 1_700_000_000_000
+SNOWFLAKE_EPOCH_MS = 1_288_834_974_657
+CORPUS_SEED = 20260104
+QUERY_SEED = 20260105
+
+
+def zipf_ranks(rng: np.random.Generator, n: int, n_clusters: int) -> np.ndarray:
+    u = rng.random(n)
+    r = np.floor(np.exp(u * np.log(n_clusters + 1.0))).astype(np.int64)
+    return np.clip(r, 1, n_clusters)  # 1-based rank
+
+
+def cluster_permutation(n_clusters: int, seed: int = 7) -> np.ndarray:
+    """rank (1-based, index r-1) -> cluster id in [1, n_clusters]."""
+    return np.random.default_rng(seed).permutation(n_clusters).astype(np.int32) + 1
+
+
+@dataclasses.dataclass
+class Corpus:
+    n_tweets: int
+    n_clusters: int
+    now_ms: int
+    # CSR posting lists: the ReadableStore[ClusterId, Seq[(TweetId, Double)]] contents
+    cluster_ids: np.ndarray   # int32 ascending (only clusters with a non-empty list)
+    list_offsets: np.ndarray  # int64 [n+1]
+    tweet_ids: np.ndarray     # int64
+    scores: np.ndarray        # float64
+    # full tweet embeddings (for quality recall): CSR by tweet
+    tweet_id_of: np.ndarray       # int64 [T] snowflake id of tweet t
+    tweet_emb_offsets: np.ndarray  # int64 [T+1]
+    tweet_emb_clusters: np.ndarray  # int32
+    tweet_emb_scores: np.ndarray    # float64
+
+    def list_of(self, cluster: int) -> Tuple[np.ndarray, np.ndarray]:
+        i = int(np.searchsorted(self.cluster_ids, cluster))
+        if i >= len(self.cluster_ids) or self.cluster_ids[i] != cluster:
+            return np.empty(0, np.int64), np.empty(0, np.float64)
+        b, e = self.list_offsets[i], self.list_offsets[i + 1]
+        return self.tweet_ids[b:e], self.scores[b:e]
+
+
+def make_corpus(n_tweets: int, n_clusters: int = N_CLUSTERS, *, seed: int = CORPUS_SEED, index_cap: int = 2000,
+                now_ms: int = NOW_MS, window_hours: int = 24, mean_clusters: float = 25.0,
+                max_clusters_per_tweet: int = 50) -> Corpus:
+    rng = np.random.default_rng(seed)
+    perm = cluster_permutation(n_clusters)
+    # tweet ids: unique Snowflake ids uniform over the window before now_ms
+    span = window_hours * 3_600_000
+    ms = now_ms - 1 - rng.integers(0, span, size=n_tweets, dtype=np.int64)
+    tid = ((ms - SNOWFLAKE_EPOCH_MS) << 22) | rng.integers(0, 1 << 22, size=n_tweets, dtype=np.int64)
+    tid = np.unique(tid)
+    while len(tid) < n_tweets:  # astronomically rare; keep ids unique
+        extra = ((now_ms - 1 - rng.integers(0, span, size=n_tweets - len(tid), dtype=np.int64) - SNOWFLAKE_EPOCH_MS) << 22) | \
+            rng.integers(0, 1 << 22, size=n_tweets - len(tid), dtype=np.int64)
+        tid = np.unique(np.concatenate([tid, extra]))
+    tid = rng.permutation(tid)
+    # clusters per tweet: min(cap, 1 + Geom(p)) with mean ~ mean_clusters
+    n_t = np.minimum(max_clusters_per_tweet, rng.geometric(1.0 / mean_clusters, size=n_tweets)).astype(np.int64)
+    tw = np.repeat(np.arange(n_tweets, dtype=np.int64), n_t)
+    cl = perm[zipf_ranks(rng, len(tw), n_clusters) - 1]
+    sc = np.maximum(np.exp(rng.normal(-2.0, 1.0, size=len(tw))), 0.001)
+    # distinct clusters per tweet: drop repeated (tweet, cluster) draws
+    key = tw * np.int64(n_clusters + 1) + cl
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    tw, cl, sc = tw[first], cl[first], sc[first]
+    # full tweet embeddings (CSR by tweet; `tw` is non-decreasing after the sort above)
+    counts = np.bincount(tw, minlength=n_tweets)
+    t_off = np.zeros(n_tweets + 1, np.int64)
+    np.cumsum(counts, out=t_off[1:])
+    # posting lists: per cluster sort by score desc (ties tweet id asc), cap
+    t_ids = tid[tw]
+    order = np.lexsort((t_ids, -sc, cl))
+    cl_s, tid_s, sc_s = cl[order], t_ids[order], sc[order]
+    uniq, start, cnt = np.unique(cl_s, return_index=True, return_counts=True)
+    pos = np.arange(len(cl_s)) - np.repeat(start, cnt)
+    keep = pos < index_cap
+    kept_cnt = np.minimum(cnt, index_cap)
+    offs = np.zeros(len(uniq) + 1, np.int64)
+    np.cumsum(kept_cnt, out=offs[1:])
+    return Corpus(n_tweets, n_clusters, now_ms, uniq.astype(np.int32), offs, np.ascontiguousarray(tid_s[keep]),
+                  np.ascontiguousarray(sc_s[keep]), tid, t_off, cl.astype(np.int32), sc)
+
+
+def make_queries(n_queries: int, n_clusters: int = N_CLUSTERS, *, seed: int = QUERY_SEED, clusters_per_user: int = 50):
+    """User embeddings: `clusters_per_user` distinct Zipf-drawn clusters, scores exp(N(0,1)).
+    Returns CSR (offsets int64[nq+1], cluster ids int32, scores float64)."""
+    rng = np.random.default_rng(seed)
+    perm = cluster_permutation(n_clusters)
+    offs = np.zeros(n_queries + 1, np.int64)
+    cids, scs = [], []
+    for q in range(n_queries):
+        got: list = []
+        seen = set()
+        while len(got) < min(clusters_per_user, n_clusters):
+            for c in perm[zipf_ranks(rng, clusters_per_user, n_clusters) - 1]:
+                if int(c) not in seen and len(got) < clusters_per_user:
+                    seen.add(int(c))
+                    got.append(int(c))
+        cids.append(np.array(got, np.int32))
+        scs.append(np.exp(rng.normal(0.0, 1.0, size=len(got))))
+        offs[q + 1] = offs[q] + len(got)
+    return offs, np.concatenate(cids) if cids else np.empty(0, np.int32), np.concatenate(scs) if scs else np.empty(0)

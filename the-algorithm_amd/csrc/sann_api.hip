@@ -1,0 +1,615 @@
+// sann_api.hip -- C ABI of the SimClusters-ANN engine (include/simclusters_ann.h): index build,
+// query preparation (the SimClustersEmbedding / fetchCandidates semantics that stay on the
+// host), launch orchestration and the general-path fallback.
+//
+// Host-side reference semantics restated here (paths relative to /root/reference/):
+//   src/scala/com/twitter/simclusters_v2/common/SimClustersEmbedding.scala:490-509  constructor
+//   .../SimClustersEmbedding.scala:377-392  truncate ; :115-125 getOrElse ; :140 contains
+//   .../CosineSimilarityUtil.scala:15-17,29-31,43-45  sumOfSquares / norm / logNorm
+//   simclusters-ann/.../candidate_source/SimClustersANNCandidateSource.scala:72-75  cluster choice
+//   simclusters-ann/.../candidate_source/ApproximateCosineSimilarity.scala:65-72    age window
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/simclusters_ann.h"
+#include "sann_device.h"
+#include "sann_kernels.h"
+#include "sann_math.h"
+
+using namespace sann;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) return fail(SANN_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = n;
+    if (n == 0) return hipSuccess;
+    return hipMalloc(&p, n);
+  }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+constexpr int64_t kSnowflakeEpochMs = 1288834974657ll;  // BQGenerationUtil.scala:150-153
+inline int64_t snowflake_first_id_for(int64_t ms) { return (int64_t)((uint64_t)(ms - kSnowflakeEpochMs) << 22); }
+
+inline int java_double_compare(double a, double b) {
+  if (a < b) return -1;
+  if (a > b) return 1;
+  uint64_t x = f64_bits(a), y = f64_bits(b);
+  if (a != a) x = 0x7ff8000000000000ull;
+  if (b != b) y = 0x7ff8000000000000ull;
+  return x == y ? 0 : ((int64_t)x < (int64_t)y ? -1 : 1);
+}
+
+uint32_t next_pow2_u32(uint64_t x) {
+  uint32_t p = 16;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+struct sann_index {
+  int device = 0;
+  int P = 1, log2P = 0, shard_id = 0, n_shards = 1;
+  std::vector<int32_t> cluster_ids;     // ascending; row = position
+  std::vector<uint32_t> h_sub_offsets;  // host copy of the device CSR
+  int64_t n_postings = 0, n_postings_total = 0;
+  int32_t max_list_len = 0;
+  DevBuf postings, ranks, sub_offsets;
+
+  IndexView view() const {
+    IndexView v;
+    v.postings = postings.as<Posting>();
+    v.ranks = ranks.as<uint32_t>();
+    v.sub_offsets = sub_offsets.as<uint32_t>();
+    v.n_rows = (int32_t)cluster_ids.size();
+    v.P = P;
+    v.log2P = log2P;
+    return v;
+  }
+  int row_of(int32_t cluster) const {
+    auto it = std::lower_bound(cluster_ids.begin(), cluster_ids.end(), cluster);
+    if (it == cluster_ids.end() || *it != cluster) return -1;
+    return (int)(it - cluster_ids.begin());
+  }
+};
+
+struct sann_batch {
+  sann_index *ix = nullptr;
+  int nq = 0, variant = 0, cap = 0, stride = 0, n_units = 0;
+  std::vector<QueryHdr> h_hdr;
+  std::vector<int32_t> h_scan_row;
+  std::vector<double> h_scan_w;
+  std::vector<int32_t> h_k;
+  DevBuf hdr, scan_row, scan_w, d_k;
+  DevBuf cand_key, cand_id, cand_cnt, unit_unique, unit_flags, status, overflow_units;
+  DevBuf out_ids, out_scores, out_counts, out_map_sizes;
+  // general path workspace
+  DevBuf g_units, g_off, g_slots, g_keys, g_dot, g_nsq;
+  int g_n = 0;
+  int64_t g_entries = 0;
+  int32_t *h_status = nullptr;  // pinned: [0] overflow units, [1] inexact queries
+  bool use_fast = false;
+  FastParams fast{};
+  sann_batch_stats_t stats{};
+  bool ran = false;
+
+  ~sann_batch() { if (h_status) (void)hipHostFree(h_status); }
+
+  BatchView view() const {
+    BatchView b;
+    b.hdr = hdr.as<QueryHdr>();
+    b.scan_row = scan_row.as<int32_t>();
+    b.scan_w = scan_w.as<double>();
+    b.nq = nq;
+    b.cap = cap;
+    b.cand_key = cand_key.as<uint64_t>();
+    b.cand_id = cand_id.as<int64_t>();
+    b.cand_cnt = cand_cnt.as<int32_t>();
+    b.unit_unique = unit_unique.as<int32_t>();
+    b.unit_flags = unit_flags.as<uint32_t>();
+    b.status = status.as<int32_t>();
+    b.overflow_units = overflow_units.as<int32_t>();
+    b.out_ids = out_ids.as<int64_t>();
+    b.out_scores = out_scores.as<double>();
+    b.out_counts = out_counts.as<int32_t>();
+    b.out_map_sizes = out_map_sizes.as<int32_t>();
+    b.stride = stride;
+    return b;
+  }
+};
+
+extern "C" {
+
+const char *sann_last_error(void) { return g_err.c_str(); }
+const char *sann_version(void) { return "simclusters_amd 0.1 (gfx950, fp64 parity layout w=16)"; }
+
+// ---------------------------------------------------------------------------------------------
+// index
+// ---------------------------------------------------------------------------------------------
+int sann_index_build(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
+                     const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores,
+                     sann_index_t **out) {
+  if (!out) return fail(SANN_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (!opts) return fail(SANN_EINVAL, "opts is NULL");
+  if (n_lists < 0 || (n_lists > 0 && (!cluster_ids || !list_offsets)))
+    return fail(SANN_EINVAL, "bad list arrays");
+  int P = opts->n_partitions == 0 ? 32 : opts->n_partitions;
+  if (P < 1 || P > 256 || (P & (P - 1))) return fail(SANN_EINVAL, "n_partitions must be a power of two in [1,256]");
+  int n_shards = opts->n_shards <= 0 ? 1 : opts->n_shards;
+  if (opts->shard_id < 0 || opts->shard_id >= n_shards) return fail(SANN_EINVAL, "shard_id out of range");
+  for (int32_t i = 1; i < n_lists; i++)
+    if (cluster_ids[i] <= cluster_ids[i - 1]) return fail(SANN_EINVAL, "cluster_ids must be ascending and unique");
+  for (int32_t i = 0; i < n_lists; i++)
+    if (list_offsets[i + 1] < list_offsets[i]) return fail(SANN_EINVAL, "list_offsets must be non-decreasing");
+  int64_t total = n_lists ? list_offsets[n_lists] - list_offsets[0] : 0;
+  if (total > 0 && (!tweet_ids || !scores)) return fail(SANN_EINVAL, "tweet_ids/scores are NULL");
+
+  sann_index *ix = new (std::nothrow) sann_index();
+  if (!ix) return fail(SANN_ENOMEM, "out of host memory");
+  ix->device = opts->device;
+  ix->P = P;
+  ix->log2P = 0;
+  while ((1 << ix->log2P) < P) ix->log2P++;
+  ix->shard_id = opts->shard_id;
+  ix->n_shards = n_shards;
+  ix->n_postings_total = total;
+  ix->cluster_ids.assign(cluster_ids, cluster_ids + n_lists);
+
+  // pass 1: count postings per (row, partition) held by this shard
+  std::vector<uint64_t> counts((size_t)n_lists * P + 1, 0);
+  int32_t max_len = 0;
+  for (int32_t r = 0; r < n_lists; r++) {
+    int64_t b = list_offsets[r], e = list_offsets[r + 1];
+    if (e - b > max_len) max_len = (int32_t)std::min<int64_t>(e - b, INT32_MAX);
+    for (int64_t i = b; i < e; i++) {
+      uint64_t h = mix64((uint64_t)tweet_ids[i]);
+      if (tweet_shard(h, (uint32_t)n_shards) != (uint32_t)ix->shard_id) continue;
+      counts[(size_t)r * P + tweet_partition(h, (uint32_t)P)]++;
+    }
+  }
+  ix->max_list_len = max_len;
+  uint64_t run = 0;
+  ix->h_sub_offsets.resize((size_t)n_lists * P + 1);
+  for (size_t i = 0; i < (size_t)n_lists * P; i++) {
+    if (run > 0xffffffffull) break;
+    ix->h_sub_offsets[i] = (uint32_t)run;
+    run += counts[i];
+  }
+  if (run > 0xfffffff0ull) {
+    delete ix;
+    return fail(SANN_ELIMIT, "more than 2^32 postings in one shard; use more shards");
+  }
+  ix->h_sub_offsets[(size_t)n_lists * P] = (uint32_t)run;
+  ix->n_postings = (int64_t)run;
+
+  // pass 2: fill, keeping list order inside every sub-list (ranks ascending)
+  std::vector<Posting> h_post((size_t)run);
+  std::vector<uint32_t> h_rank((size_t)run);
+  std::vector<uint32_t> cursor(ix->h_sub_offsets.begin(), ix->h_sub_offsets.end() - 1);
+  for (int32_t r = 0; r < n_lists; r++) {
+    int64_t b = list_offsets[r], e = list_offsets[r + 1];
+    for (int64_t i = b; i < e; i++) {
+      uint64_t h = mix64((uint64_t)tweet_ids[i]);
+      if (tweet_shard(h, (uint32_t)n_shards) != (uint32_t)ix->shard_id) continue;
+      uint32_t &c = cursor[(size_t)r * P + tweet_partition(h, (uint32_t)P)];
+      h_post[c].id = tweet_ids[i];
+      h_post[c].score = scores[i];
+      h_rank[c] = (uint32_t)std::min<int64_t>(i - b, 0xffffffffll);
+      c++;
+    }
+  }
+
+  hipError_t e = hipSetDevice(ix->device);
+  if (e == hipSuccess) e = ix->postings.alloc(std::max<size_t>(h_post.size(), 1) * sizeof(Posting));
+  if (e == hipSuccess) e = ix->ranks.alloc(std::max<size_t>(h_rank.size(), 1) * sizeof(uint32_t));
+  if (e == hipSuccess) e = ix->sub_offsets.alloc(ix->h_sub_offsets.size() * sizeof(uint32_t));
+  if (e == hipSuccess && !h_post.empty())
+    e = hipMemcpy(ix->postings.p, h_post.data(), h_post.size() * sizeof(Posting), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !h_rank.empty())
+    e = hipMemcpy(ix->ranks.p, h_rank.data(), h_rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMemcpy(ix->sub_offsets.p, ix->h_sub_offsets.data(), ix->h_sub_offsets.size() * sizeof(uint32_t),
+                  hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    delete ix;
+    return fail(SANN_EDEVICE, std::string("index upload: ") + hipGetErrorString(e));
+  }
+  *out = ix;
+  return SANN_OK;
+}
+
+int sann_index_info(const sann_index_t *ix, sann_index_info_t *info) {
+  if (!ix || !info) return fail(SANN_EINVAL, "NULL argument");
+  info->n_clusters = (int64_t)ix->cluster_ids.size();
+  info->n_postings = ix->n_postings;
+  info->n_postings_total = ix->n_postings_total;
+  info->device_bytes = (int64_t)(ix->postings.bytes + ix->ranks.bytes + ix->sub_offsets.bytes);
+  info->n_partitions = ix->P;
+  info->shard_id = ix->shard_id;
+  info->n_shards = ix->n_shards;
+  info->max_list_len = ix->max_list_len;
+  return SANN_OK;
+}
+
+int sann_index_get_list(const sann_index_t *ix, int32_t cluster_id, int64_t cap, int64_t *tweet_ids, double *scores,
+                        int32_t *ranks, int64_t *n) {
+  if (!ix || !n) return fail(SANN_EINVAL, "NULL argument");
+  *n = 0;
+  int row = ix->row_of(cluster_id);
+  if (row < 0) return SANN_OK;
+  uint32_t b = ix->h_sub_offsets[(size_t)row * ix->P], e = ix->h_sub_offsets[(size_t)(row + 1) * ix->P];
+  int64_t len = (int64_t)e - b;
+  *n = len;
+  if (len == 0 || cap <= 0) return SANN_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  std::vector<Posting> p((size_t)len);
+  std::vector<uint32_t> r((size_t)len);
+  HIP_TRY(hipMemcpy(p.data(), ix->postings.as<Posting>() + b, (size_t)len * sizeof(Posting), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(r.data(), ix->ranks.as<uint32_t>() + b, (size_t)len * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  // sub-lists are concatenated partition by partition; give them back in list (rank) order
+  std::vector<int64_t> order((size_t)len);
+  for (int64_t i = 0; i < len; i++) order[(size_t)i] = i;
+  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t c) { return r[(size_t)a] < r[(size_t)c]; });
+  for (int64_t i = 0; i < len && i < cap; i++) {
+    size_t o = (size_t)order[(size_t)i];
+    if (tweet_ids) tweet_ids[i] = p[o].id;
+    if (scores) scores[i] = p[o].score;
+    if (ranks) ranks[i] = (int32_t)r[o];
+  }
+  return SANN_OK;
+}
+
+int sann_index_destroy(sann_index_t *ix) {
+  if (!ix) return SANN_OK;
+  (void)hipSetDevice(ix->device);
+  delete ix;
+  return SANN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch
+// ---------------------------------------------------------------------------------------------
+int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t nq, const int64_t *emb_offsets,
+                      const int32_t *emb_cluster_ids, const double *emb_scores, const int64_t *source_tweet_ids,
+                      const uint8_t *has_source_tweet, const sann_config_t *configs, int32_t n_configs,
+                      const int64_t *scan_offsets, const int32_t *scan_cluster_ids, sann_batch_t **out) {
+  if (!out) return fail(SANN_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (!ix) return fail(SANN_EINVAL, "index is NULL");
+  if (nq < 0) return fail(SANN_EINVAL, "nq < 0");
+  if (variant < 0 || variant > 2) return fail(SANN_EINVAL, "unknown variant");
+  if (nq > 0 && (!emb_offsets || !configs)) return fail(SANN_EINVAL, "emb_offsets/configs are NULL");
+  if (n_configs != 1 && n_configs != nq) return fail(SANN_EINVAL, "n_configs must be 1 or nq");
+  if ((scan_offsets == nullptr) != (scan_cluster_ids == nullptr) && nq > 0 && scan_offsets &&
+      scan_offsets[nq] != scan_offsets[0])
+    return fail(SANN_EINVAL, "scan_offsets and scan_cluster_ids must be given together");
+  if ((int64_t)nq * ix->P > (int64_t)INT32_MAX / 2) return fail(SANN_ELIMIT, "nq * n_partitions too large");
+
+  sann_batch *b = new (std::nothrow) sann_batch();
+  if (!b) return fail(SANN_ENOMEM, "out of host memory");
+  struct Guard { sann_batch *b; ~Guard() { delete b; } } guard{b};
+  b->ix = ix;
+  b->nq = nq;
+  b->variant = variant;
+  b->n_units = nq * ix->P;
+  b->h_hdr.resize((size_t)nq);
+  b->h_k.resize((size_t)nq);
+
+  struct IdScore { int32_t id; double score; };
+  std::vector<IdScore> emb, by_id;
+  std::vector<int32_t> keys;
+  int kmax = 1;
+  int64_t postings_scanned = 0, alg_bytes = 0;
+  std::vector<uint64_t> unit_bound((size_t)b->n_units, 0);
+
+  for (int32_t q = 0; q < nq; q++) {
+    const sann_config_t &cfg = configs[n_configs == 1 ? 0 : q];
+    int64_t eb = emb_offsets[q], ee = emb_offsets[q + 1];
+    if (ee < eb) return fail(SANN_EINVAL, "emb_offsets must be non-decreasing");
+    if (ee > eb && (!emb_cluster_ids || !emb_scores)) return fail(SANN_EINVAL, "embedding arrays are NULL");
+    // SimClustersEmbedding constructor: drop score <= 0, order by (score desc, cluster id asc)
+    emb.clear();
+    for (int64_t i = eb; i < ee; i++)
+      if (emb_scores[i] > 0.0) emb.push_back({emb_cluster_ids[i], emb_scores[i]});
+    std::sort(emb.begin(), emb.end(), [](const IdScore &x, const IdScore &y) {
+      int c = java_double_compare(y.score, x.score);
+      if (c) return c < 0;
+      return x.id < y.id;
+    });
+    by_id = emb;
+    std::stable_sort(by_id.begin(), by_id.end(), [](const IdScore &x, const IdScore &y) { return x.id < y.id; });
+    // CosineSimilarityUtil.sumOfSquaresArray over sortedScores (left fold)
+    double sumsq = 0.0;
+    for (const IdScore &x : by_id) sumsq = sumsq + x.score * x.score;
+
+    QueryHdr &h = b->h_hdr[(size_t)q];
+    h.l2norm = std::sqrt(sumsq);
+    h.lognorm = strict_log(sumsq + 1);
+    h.min_score = cfg.min_score;
+    h.M = cfg.max_top_tweets_per_cluster < 0 ? 0 : cfg.max_top_tweets_per_cluster;
+    int k = cfg.max_num_results < 1000 ? cfg.max_num_results : 1000;
+    h.k = k < 0 ? 0 : k;
+    b->h_k[(size_t)q] = h.k;
+    kmax = std::max(kmax, h.k);
+    h.alg = cfg.ann_algorithm;
+    // age window (ApproximateCosineSimilarity.scala:65-72)
+    h.earliest = cfg.max_tweet_candidate_age_hours >= 175200
+                     ? 0
+                     : snowflake_first_id_for(now_ms - (int64_t)cfg.max_tweet_candidate_age_hours * 3600000ll);
+    h.latest = snowflake_first_id_for(now_ms - (int64_t)cfg.min_tweet_candidate_age_hours * 3600000ll);
+    // source-tweet exclusion (:90 ; Optimized :56,:67 ; Experimental :59,:70)
+    bool has_src = has_source_tweet && has_source_tweet[q] && source_tweet_ids;
+    if (variant == SANN_VARIANT_ORIGINAL) {
+      h.excl_enabled = has_src ? 1 : 0;
+      h.src_excl = has_src ? source_tweet_ids[q] : 0;
+    } else {
+      h.excl_enabled = 1;
+      h.src_excl = has_src ? source_tweet_ids[q] : 0;
+    }
+
+    // keys of clusterTweetsMap in accumulation order
+    keys.clear();
+    if (scan_offsets) {
+      for (int64_t i = scan_offsets[q]; i < scan_offsets[q + 1]; i++) keys.push_back(scan_cluster_ids[i]);
+    } else {
+      // truncate(maxScanClusters).getClusterIds().toSet -> ascending cluster id
+      int64_t n = cfg.max_scan_clusters < 0 ? 0 : std::min<int64_t>((int64_t)emb.size(), cfg.max_scan_clusters);
+      for (int64_t i = 0; i < n; i++) keys.push_back(emb[(size_t)i].id);
+      std::sort(keys.begin(), keys.end());
+    }
+    h.scan_begin = (int32_t)b->h_scan_row.size();
+    for (int32_t cluster : keys) {
+      auto it = std::lower_bound(by_id.begin(), by_id.end(), cluster,
+                                 [](const IdScore &x, int32_t c) { return x.id < c; });
+      bool contained = it != by_id.end() && it->id == cluster;
+      if (!contained && variant != SANN_VARIANT_EXPERIMENTAL) continue;  // `if sourceEmbedding.contains(clusterId)`
+      double w = contained ? it->score : 0.0;                             // getOrElse(clusterId)
+      int row = ix->row_of(cluster);
+      if (row < 0) continue;  // None in clusterTweetsMap
+      b->h_scan_row.push_back(row);
+      b->h_scan_w.push_back(w);
+      uint64_t bound_sum = 0;
+      for (int p = 0; p < ix->P; p++) {
+        uint64_t len = ix->h_sub_offsets[(size_t)row * ix->P + p + 1] - ix->h_sub_offsets[(size_t)row * ix->P + p];
+        uint64_t lim = std::min<uint64_t>(len, (uint64_t)h.M);
+        unit_bound[(size_t)q * ix->P + p] += lim;
+        bound_sum += lim;
+      }
+      // exact when this shard holds whole lists: min(len_c, M) postings have rank < M
+      uint64_t whole = ix->h_sub_offsets[(size_t)(row + 1) * ix->P] - ix->h_sub_offsets[(size_t)row * ix->P];
+      postings_scanned += (int64_t)(ix->n_shards == 1 ? std::min<uint64_t>(whole, (uint64_t)h.M) : bound_sum);
+    }
+    h.n_scan = (int32_t)b->h_scan_row.size() - h.scan_begin;
+    alg_bytes += (int64_t)h.n_scan * 12;
+  }
+  // postings_scanned = sum_c min(len_c, M) (SURVEY 8d's P_q) when the shard holds whole lists;
+  // with tweet-hash shards it is the per-sub-list upper bound sum_p min(len_p, M).
+  b->stats.postings_scanned = postings_scanned;
+  b->stats.algorithmic_bytes = alg_bytes + postings_scanned * 16;
+  b->stats.n_units = b->n_units;
+
+  b->cap = kmax;
+  b->stride = kmax;
+
+  HIP_TRY(hipSetDevice(ix->device));
+  size_t nu = (size_t)std::max(b->n_units, 1), nqz = (size_t)std::max(nq, 1);
+  HIP_TRY(b->hdr.alloc(nqz * sizeof(QueryHdr)));
+  HIP_TRY(b->scan_row.alloc(std::max<size_t>(b->h_scan_row.size(), 1) * 4));
+  HIP_TRY(b->scan_w.alloc(std::max<size_t>(b->h_scan_w.size(), 1) * 8));
+  HIP_TRY(b->d_k.alloc(nqz * 4));
+  HIP_TRY(b->cand_key.alloc(nu * (size_t)b->cap * 8));
+  HIP_TRY(b->cand_id.alloc(nu * (size_t)b->cap * 8));
+  HIP_TRY(b->cand_cnt.alloc(nu * 4));
+  HIP_TRY(b->unit_unique.alloc(nu * 4));
+  HIP_TRY(b->unit_flags.alloc(nu * 4));
+  HIP_TRY(b->status.alloc((nqz + 2) * 4));
+  HIP_TRY(b->overflow_units.alloc(nu * 4));
+  HIP_TRY(b->out_ids.alloc(nqz * (size_t)b->stride * 8));
+  HIP_TRY(b->out_scores.alloc(nqz * (size_t)b->stride * 8));
+  HIP_TRY(b->out_counts.alloc(nqz * 4));
+  HIP_TRY(b->out_map_sizes.alloc(nqz * 4));
+  HIP_TRY(hipHostMalloc((void **)&b->h_status, (nqz + 2) * 4, hipHostMallocDefault));
+  if (nq > 0) {
+    HIP_TRY(hipMemcpy(b->hdr.p, b->h_hdr.data(), (size_t)nq * sizeof(QueryHdr), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_k.p, b->h_k.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
+  }
+  if (!b->h_scan_row.empty()) {
+    HIP_TRY(hipMemcpy(b->scan_row.p, b->h_scan_row.data(), b->h_scan_row.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->scan_w.p, b->h_scan_w.data(), b->h_scan_w.size() * 8, hipMemcpyHostToDevice));
+  }
+
+  // general-path workspace for every unit (the fast path, when enabled, only needs it for the
+  // units it flags; those regions are sized from the same bounds)
+  const char *force = getenv("SANN_FORCE_GENERAL");
+  b->use_fast = false;
+  (void)force;
+  {
+    std::vector<int64_t> off((size_t)b->n_units);
+    std::vector<uint32_t> slots((size_t)b->n_units);
+    int64_t run = 0;
+    for (int u = 0; u < b->n_units; u++) {
+      uint32_t S = next_pow2_u32(2 * unit_bound[(size_t)u] + 1);
+      off[(size_t)u] = run;
+      slots[(size_t)u] = S;
+      run += (int64_t)S + 1;
+    }
+    b->g_n = b->n_units;
+    b->g_entries = run;
+    HIP_TRY(b->g_off.alloc(nu * 8));
+    HIP_TRY(b->g_slots.alloc(nu * 4));
+    HIP_TRY(b->g_keys.alloc((size_t)std::max<int64_t>(run, 1) * 8));
+    HIP_TRY(b->g_dot.alloc((size_t)std::max<int64_t>(run, 1) * 8));
+    HIP_TRY(b->g_nsq.alloc((size_t)std::max<int64_t>(run, 1) * 8));
+    if (b->n_units > 0) {
+      HIP_TRY(hipMemcpy(b->g_off.p, off.data(), (size_t)b->n_units * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(b->g_slots.p, slots.data(), (size_t)b->n_units * 4, hipMemcpyHostToDevice));
+    }
+  }
+  guard.b = nullptr;
+  *out = b;
+  return SANN_OK;
+}
+
+int sann_batch_run(sann_batch_t *b, void *hip_stream) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(hipSetDevice(b->ix->device));
+  if (b->nq == 0) { b->ran = true; return SANN_OK; }
+  IndexView ixv = b->ix->view();
+  BatchView bv = b->view();
+  HIP_TRY(hipMemsetAsync(b->status.p, 0, ((size_t)b->nq + 2) * 4, st));
+  // general path over every unit
+  HIP_TRY(hipMemsetAsync(b->g_keys.p, 0xFF, (size_t)b->g_entries * 8, st));
+  GeneralWs ws;
+  ws.units = nullptr;
+  ws.ws_off = b->g_off.as<int64_t>();
+  ws.ws_slots = b->g_slots.as<uint32_t>();
+  ws.keys = b->g_keys.as<int64_t>();
+  ws.dot = b->g_dot.as<double>();
+  ws.nsq = b->g_nsq.as<double>();
+  HIP_TRY(launch_unit_general(ixv, bv, ws, b->n_units, st));
+  HIP_TRY(launch_merge(ixv, bv, nullptr, b->nq, st));
+  HIP_TRY(hipMemcpyAsync(b->h_status, b->status.p, 2 * 4, hipMemcpyDeviceToHost, st));
+  b->ran = true;
+  return SANN_OK;
+}
+
+int sann_batch_finish(sann_batch_t *b, void *hip_stream) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  if (!b->ran) return fail(SANN_EINVAL, "sann_batch_run was not called");
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(hipSetDevice(b->ix->device));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (b->nq == 0) return SANN_OK;
+  if (b->h_status[0] != 0 || b->h_status[1] != 0)
+    return fail(SANN_EINTERNAL, "general path reported overflow/inexact units");
+  return SANN_OK;
+}
+
+int sann_batch_results(sann_batch_t *b, int64_t *out_ids, double *out_scores, int32_t out_stride, int32_t *out_counts,
+                       int32_t *out_map_sizes) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  if (b->nq == 0) return SANN_OK;
+  if (out_stride < b->stride) return fail(SANN_EINVAL, "out_stride smaller than the batch's max k");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  if (out_ids)
+    HIP_TRY(hipMemcpy2D(out_ids, (size_t)out_stride * 8, b->out_ids.p, (size_t)b->stride * 8, (size_t)b->stride * 8,
+                        (size_t)b->nq, hipMemcpyDeviceToHost));
+  if (out_scores)
+    HIP_TRY(hipMemcpy2D(out_scores, (size_t)out_stride * 8, b->out_scores.p, (size_t)b->stride * 8,
+                        (size_t)b->stride * 8, (size_t)b->nq, hipMemcpyDeviceToHost));
+  if (out_counts) HIP_TRY(hipMemcpy(out_counts, b->out_counts.p, (size_t)b->nq * 4, hipMemcpyDeviceToHost));
+  if (out_map_sizes) HIP_TRY(hipMemcpy(out_map_sizes, b->out_map_sizes.p, (size_t)b->nq * 4, hipMemcpyDeviceToHost));
+  return SANN_OK;
+}
+
+int sann_batch_device_results(sann_batch_t *b, void **d_ids, void **d_scores, void **d_counts, void **d_map_sizes,
+                              int32_t *stride) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  if (d_ids) *d_ids = b->out_ids.p;
+  if (d_scores) *d_scores = b->out_scores.p;
+  if (d_counts) *d_counts = b->out_counts.p;
+  if (d_map_sizes) *d_map_sizes = b->out_map_sizes.p;
+  if (stride) *stride = b->stride;
+  return SANN_OK;
+}
+
+int sann_batch_device_k(sann_batch_t *b, void **d_k) {
+  if (!b || !d_k) return fail(SANN_EINVAL, "NULL argument");
+  *d_k = b->d_k.p;
+  return SANN_OK;
+}
+
+int sann_batch_stats(sann_batch_t *b, sann_batch_stats_t *stats) {
+  if (!b || !stats) return fail(SANN_EINVAL, "NULL argument");
+  *stats = b->stats;
+  return SANN_OK;
+}
+
+int sann_batch_destroy(sann_batch_t *b) {
+  if (!b) return SANN_OK;
+  (void)hipSetDevice(b->ix->device);
+  delete b;
+  return SANN_OK;
+}
+
+int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_ms, int32_t nq,
+                              const int64_t *emb_offsets, const int32_t *emb_cluster_ids, const double *emb_scores,
+                              const int64_t *source_tweet_ids, const uint8_t *has_source_tweet,
+                              const sann_config_t *configs, int32_t n_configs, const int64_t *scan_offsets,
+                              const int32_t *scan_cluster_ids, int64_t *out_ids, double *out_scores,
+                              int32_t out_stride, int32_t *out_counts, int32_t *out_map_sizes) {
+  sann_batch_t *b = nullptr;
+  int rc = sann_batch_create(index, variant, now_ms, nq, emb_offsets, emb_cluster_ids, emb_scores, source_tweet_ids,
+                             has_source_tweet, configs, n_configs, scan_offsets, scan_cluster_ids, &b);
+  if (rc != SANN_OK) return rc;
+  rc = sann_batch_run(b, nullptr);
+  if (rc == SANN_OK) rc = sann_batch_finish(b, nullptr);
+  if (rc == SANN_OK) rc = sann_batch_results(b, out_ids, out_scores, out_stride, out_counts, out_map_sizes);
+  std::string keep = g_err;
+  sann_batch_destroy(b);
+  if (rc != SANN_OK) g_err = keep;
+  return rc;
+}
+
+int sann_merge_shards(int32_t device, void *hip_stream, int32_t n_shards, int32_t nq, int32_t stride, const void *d_ids,
+                      const void *d_scores, const void *d_counts, const void *d_map_sizes, const void *d_k,
+                      void *d_out_ids, void *d_out_scores, void *d_out_counts, void *d_out_map_sizes) {
+  if (n_shards < 1 || nq < 0 || stride < 1 || stride > 1024) return fail(SANN_EINVAL, "bad merge sizes");
+  if (nq == 0) return SANN_OK;
+  if (!d_ids || !d_scores || !d_counts || !d_map_sizes || !d_k || !d_out_ids || !d_out_scores || !d_out_counts ||
+      !d_out_map_sizes)
+    return fail(SANN_EINVAL, "NULL device pointer");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(launch_merge_shards(n_shards, nq, stride, (const int64_t *)d_ids, (const double *)d_scores,
+                              (const int32_t *)d_counts, (const int32_t *)d_map_sizes, (const int32_t *)d_k,
+                              (int64_t *)d_out_ids, (double *)d_out_scores, (int32_t *)d_out_counts,
+                              (int32_t *)d_out_map_sizes, (hipStream_t)hip_stream));
+  return SANN_OK;
+}
+
+int sann_debug_normalise(int32_t device, int32_t alg, int32_t n, const double *dot, const double *nsq, double l2norm,
+                         double lognorm, double *out) {
+  if (n < 0 || (n > 0 && (!dot || !nsq || !out))) return fail(SANN_EINVAL, "bad arguments");
+  if (n == 0) return SANN_OK;
+  HIP_TRY(hipSetDevice(device));
+  DevBuf a, b, c;
+  HIP_TRY(a.alloc((size_t)n * 8));
+  HIP_TRY(b.alloc((size_t)n * 8));
+  HIP_TRY(c.alloc((size_t)n * 8));
+  HIP_TRY(hipMemcpy(a.p, dot, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b.p, nsq, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(launch_debug_normalise(alg, n, a.as<double>(), b.as<double>(), l2norm, lognorm, c.as<double>(), nullptr));
+  HIP_TRY(hipMemcpy(out, c.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return SANN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// sann_device.h -- data layout shared by the host side and the gfx950 kernels.
+//
+// HBM layout of a cluster -> top-tweets index shard (see DESIGN.md "Data layout"):
+//
+//   postings[n_postings]        {int64 tweet_id; double score}  16 B, AoS so that one lane = one
+//                               global_load_dwordx4 and a wave instruction covers 1 KiB contiguous
+//   ranks[n_postings]           uint32: position of the posting in the cluster's full list as the
+//                               store returned it (the `i` of ApproximateCosineSimilarity.scala:87)
+//   sub_offsets[n_rows*P + 1]   uint32 CSR: sub-list (row, p) = postings of cluster `row` whose
+//                               tweet hashes to partition p (and to this shard), in rank order
+//
+// Every posting of one tweet lives in the same (shard, partition), so a (query, partition) work
+// unit can aggregate, normalise and select on its own; partitions and shards are merged by an
+// exact top-k merge (the ComposedQueryable pattern, ann/.../common/ShardApi.scala:71-87).
+#pragma once
+#include <stdint.h>
+
+namespace sann {
+
+struct Posting {
+  int64_t id;
+  double score;
+};
+
+// Prepared query (host side applies the SimClustersEmbedding / fetchCandidates semantics).
+struct QueryHdr {
+  int64_t src_excl;   // tweet id to exclude when excl_enabled
+  int64_t earliest;   // ApproximateCosineSimilarity.scala:66-70
+  int64_t latest;     // :71-72
+  double l2norm;      // sourceEmbedding.l2norm   (full embedding, SimClustersEmbedding.scala:61)
+  double lognorm;     // sourceEmbedding.logNorm  (:63)
+  double min_score;   // config.minScore
+  int32_t scan_begin; // offset into scan_row / scan_w
+  int32_t n_scan;     // clusters to scan, in accumulation order
+  int32_t M;          // max(maxTopTweetsPerCluster, 0)
+  int32_t k;          // min(max(maxNumResults,0), 1000)
+  int32_t alg;        // SANN_ALG_*
+  int32_t excl_enabled;
+};
+
+struct IndexView {
+  const Posting *postings;
+  const uint32_t *ranks;
+  const uint32_t *sub_offsets;
+  int32_t n_rows;
+  int32_t P;      // partitions (power of two)
+  int32_t log2P;
+};
+
+// Unit flags
+enum : uint32_t {
+  UNIT_OK = 0,
+  UNIT_OVERFLOW = 1,   // fast path could not hold the unit (table, dup list or scan list too big)
+  UNIT_TRUNCATED = 2,  // unit had more qualifying candidates than it emitted
+};
+
+struct BatchView {
+  const QueryHdr *hdr;
+  const int32_t *scan_row;
+  const double *scan_w;
+  int32_t nq;
+  int32_t cap;              // entries per unit in cand_* (>= max k of the batch)
+  // per unit outputs
+  uint64_t *cand_key;       // [n_units*cap] monotone score key
+  int64_t *cand_id;         // [n_units*cap]
+  int32_t *cand_cnt;        // [n_units]
+  int32_t *unit_unique;     // [n_units] distinct tweets accumulated (candidateScoresMap.size share)
+  uint32_t *unit_flags;     // [n_units]
+  // batch status: [0] = number of overflowed units, [1] = number of inexact queries
+  int32_t *status;
+  int32_t *overflow_units;  // [n_units] list of overflowed unit ids (first status[0] entries)
+  // final per-query outputs
+  int64_t *out_ids;         // [nq*stride]
+  double *out_scores;       // [nq*stride]
+  int32_t *out_counts;      // [nq]
+  int32_t *out_map_sizes;   // [nq]
+  int32_t stride;
+};
+
+// Workspace of the general (global-memory table) path, one region per listed unit.
+struct GeneralWs {
+  const int32_t *units;     // unit ids to process (NULL = identity)
+  const int64_t *ws_off;    // [n] entry offset of the unit's table
+  const uint32_t *ws_slots; // [n] power-of-two slot count S (table has S+1 entries)
+  int64_t *keys;
+  double *dot;
+  double *nsq;
+};
+
+constexpr int64_t kEmptyKey = -1;  // table sentinel (memset 0xFF); a real tweet id of -1 uses slot S
+
+__host__ __device__ inline uint64_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+// tweet -> (shard, partition).  Shard from the high bits, partition from the low bits, table
+// slot from the middle bits, so the three are independent.
+__host__ __device__ inline uint32_t tweet_shard(uint64_t h, uint32_t n_shards) { return (uint32_t)((h >> 40) % n_shards); }
+__host__ __device__ inline uint32_t tweet_partition(uint64_t h, uint32_t P) { return (uint32_t)(h & (P - 1)); }
+__host__ __device__ inline uint32_t tweet_slot(uint64_t h) { return (uint32_t)(h >> 12); }
+
+}  // namespace sann

@@ -1,0 +1,29 @@
+// sann_kernels.h -- host-callable launchers of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sann_device.h"
+
+namespace sann {
+
+hipError_t launch_unit_general(const IndexView &ix, const BatchView &b, const GeneralWs &ws, int n_units,
+                               hipStream_t stream);
+hipError_t launch_merge(const IndexView &ix, const BatchView &b, const int32_t *query_list, int n_queries,
+                        hipStream_t stream);
+hipError_t launch_merge_shards(int n_shards, int nq, int stride, const int64_t *ids, const double *scores,
+                               const int32_t *counts, const int32_t *map_sizes, const int32_t *k, int64_t *out_ids,
+                               double *out_scores, int32_t *out_counts, int32_t *out_map_sizes, hipStream_t stream);
+
+hipError_t launch_debug_normalise(int alg, int n, const double *dot, const double *nsq, double l2norm, double lognorm,
+                                  double *out, hipStream_t stream);
+
+// LDS fast path (sann_fast.hip).  Returns hipErrorInvalidValue when the configuration cannot
+// run on the fast path at all (the caller then uses the general path for every unit).
+struct FastParams {
+  int table_slots;  // LDS hash slots per unit (power of two)
+  int k_local;      // entries a unit must emit before it may truncate
+};
+hipError_t launch_unit_fast(const IndexView &ix, const BatchView &b, const FastParams &fp, int n_units,
+                            hipStream_t stream);
+
+}  // namespace sann

@@ -1,0 +1,446 @@
+// sann_kernels.hip -- gfx950 kernels of the SimClusters-ANN hot path.
+//
+// Reference semantics (paths relative to /root/reference/):
+//   simclusters-ann/server/src/main/scala/com/twitter/simclustersann/candidate_source/
+//     ApproximateCosineSimilarity.scala:83-127   accumulate, normalise, filter, sort, take
+//
+// Kernels in this file
+//   unit_general_kernel  one workgroup per (query, partition) unit; hash table in global memory,
+//                        clusters accumulated in order with a workgroup barrier between them.
+//                        Always correct for any size / duplication; it is the fallback of the
+//                        LDS fast path (sann_fast.hip) and the first path that was parity-green.
+//   merge_kernel         one workgroup per query: exact top-k over the units' candidates under
+//                        the total order (score desc by Double.compare, tweet id asc), bitonic
+//                        sort of the k winners in LDS, final outputs.
+//   merge_shards_kernel  the same merge over all-gathered per-shard results.
+//
+// Compiled with -ffp-contract=off (see sann_math.h).
+#include <hip/hip_runtime.h>
+
+#include "sann_device.h"
+#include "sann_kernels.h"
+#include "sann_math.h"
+
+namespace sann {
+
+constexpr int WG = 256;
+constexpr int KMAX = 1024;  // >= MaxNumResultsUpperBound (1000), ApproximateCosineSimilarity.scala:41
+
+// ---------------------------------------------------------------------------------------------
+// normalisation, ApproximateCosineSimilarity.scala:111-119
+// ---------------------------------------------------------------------------------------------
+__device__ inline double normalise(int alg, double dot, double nsq, double l2norm, double lognorm) {
+  switch (alg) {
+    case 3: return dot / lognorm / strict_log(1 + nsq);
+    case 2: return dot / l2norm / sqrt(nsq);
+    case 4: return dot / sqrt(nsq);
+    case 1: return dot;
+    default: return __builtin_nan("");  // scala MatchError; never >= minScore
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact top-k threshold by MSB-first radix select over the 128-bit key (score_key, id_key)
+// ---------------------------------------------------------------------------------------------
+__device__ inline bool prefix_match(uint64_t hi, uint64_t lo, uint64_t phi, uint64_t plo, int pass) {
+  if (pass == 0) return true;
+  if (pass < 8) {
+    int sh = 64 - 8 * pass;
+    return (hi >> sh) == (phi >> sh);
+  }
+  if (pass == 8) return hi == phi;
+  int sh = 128 - 8 * pass;  // 56..8
+  return hi == phi && (lo >> sh) == (plo >> sh);
+}
+__device__ inline unsigned digit_of(uint64_t hi, uint64_t lo, int pass) {
+  return pass < 8 ? (unsigned)((hi >> (56 - 8 * pass)) & 0xff) : (unsigned)((lo >> (56 - 8 * (pass - 8))) & 0xff);
+}
+__device__ inline bool key_ge(uint64_t hi, uint64_t lo, uint64_t thi, uint64_t tlo) {
+  return hi > thi || (hi == thi && lo >= tlo);
+}
+
+// Src: int size(); bool get(int i, uint64_t& hi, uint64_t& lo)  (false = slot not a candidate)
+// After the call every candidate with key >= (thr_hi, thr_lo) is in the top-k and there are
+// exactly min(k, n_valid) of them.  s_hist: 256 uints, s_ctl: 4 ints, both in LDS.
+template <class Src>
+__device__ void wg_select_threshold(const Src &src, int k, unsigned *s_hist, int *s_ctl, uint64_t &thr_hi,
+                                    uint64_t &thr_lo, int &n_valid) {
+  const int tid = threadIdx.x;
+  const int n = src.size();
+  if (tid == 0) s_ctl[0] = 0;
+  __syncthreads();
+  int local = 0;
+  for (int i = tid; i < n; i += WG) {
+    uint64_t hi, lo;
+    if (src.get(i, hi, lo)) local++;
+  }
+  if (local) atomicAdd(&s_ctl[0], local);
+  __syncthreads();
+  n_valid = s_ctl[0];
+  thr_hi = 0;
+  thr_lo = 0;
+  if (n_valid <= k || k <= 0) {
+    if (k <= 0) { thr_hi = ~0ull; thr_lo = ~0ull; }
+    __syncthreads();
+    return;
+  }
+  uint64_t phi = 0, plo = 0;
+  int need = k;
+  for (int pass = 0; pass < 16; pass++) {
+    for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += WG) {
+      uint64_t hi, lo;
+      if (src.get(i, hi, lo) && prefix_match(hi, lo, phi, plo, pass)) atomicAdd(&s_hist[digit_of(hi, lo, pass)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int cum = 0;
+      for (int d = 255; d >= 0; d--) {
+        int c = (int)s_hist[d];
+        if (cum + c >= need) {
+          s_ctl[1] = d;
+          s_ctl[2] = need - cum;
+          s_ctl[3] = (c == need - cum);
+          break;
+        }
+        cum += c;
+      }
+    }
+    __syncthreads();
+    uint64_t d = (uint64_t)s_ctl[1];
+    need = s_ctl[2];
+    int done = s_ctl[3];
+    if (pass < 8) phi |= d << (56 - 8 * pass);
+    else plo |= d << (56 - 8 * (pass - 8));
+    __syncthreads();
+    if (done) break;
+  }
+  thr_hi = phi;
+  thr_lo = plo;
+}
+
+// Bitonic sort, descending by (hi, lo), n a power of two, arrays in LDS.
+__device__ void bitonic_sort_desc(uint64_t *hi, uint64_t *lo, int n) {
+  const int tid = threadIdx.x;
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (n >> 1); t += WG) {
+        int i = 2 * t - (t & (stride - 1));
+        int j = i + stride;
+        bool desc = ((i & size) == 0);
+        uint64_t ah = hi[i], al = lo[i], bh = hi[j], bl = lo[j];
+        bool a_lt_b = ah < bh || (ah == bh && al < bl);
+        bool swap = desc ? a_lt_b : !a_lt_b && !(ah == bh && al == bl);
+        if (swap) {
+          hi[i] = bh; lo[i] = bl;
+          hi[j] = ah; lo[j] = al;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ inline int next_pow2(int x) {
+  int p = 2;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// General unit kernel: global-memory table, ordered rounds.
+// ---------------------------------------------------------------------------------------------
+__device__ inline int lower_bound_u32(const uint32_t *a, int n, uint32_t v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+struct TableSrc {
+  const int64_t *keys;
+  const double *dot;  // holds score_key bits after finalize
+  const double *nsq;  // 1.0 = candidate, 0.0 = not
+  int n;
+  __device__ int size() const { return n; }
+  __device__ bool get(int i, uint64_t &hi, uint64_t &lo) const {
+    if (nsq[i] != 1.0) return false;
+    hi = f64_bits(dot[i]);
+    lo = id_key(keys[i]);
+    return true;
+  }
+};
+
+__global__ __launch_bounds__(WG) void unit_general_kernel(IndexView ix, BatchView b, GeneralWs ws) {
+  __shared__ unsigned s_hist[256];
+  __shared__ int s_ctl[4];
+  __shared__ int s_special, s_cnt, s_unique;
+
+  const int tid = threadIdx.x;
+  const int blk = blockIdx.x;
+  const int unit = ws.units ? ws.units[blk] : blk;
+  const int q = unit >> ix.log2P;
+  const int p = unit & (ix.P - 1);
+  const QueryHdr h = b.hdr[q];
+  const uint32_t S = ws.ws_slots[blk];
+  int64_t *keys = ws.keys + ws.ws_off[blk];
+  double *dot = ws.dot + ws.ws_off[blk];
+  double *nsq = ws.nsq + ws.ws_off[blk];
+
+  if (tid == 0) { s_special = 0; s_cnt = 0; s_unique = 0; }
+  __syncthreads();
+
+  // ApproximateCosineSimilarity.scala:83-100, clusters in the prepared (accumulation) order
+  for (int c = 0; c < h.n_scan; c++) {
+    const int row = b.scan_row[h.scan_begin + c];
+    const double w = b.scan_w[h.scan_begin + c];
+    const uint32_t base = ix.sub_offsets[(int64_t)row * ix.P + p];
+    const uint32_t end = ix.sub_offsets[(int64_t)row * ix.P + p + 1];
+    // postings with rank < M form a prefix of the sub-list (:87)
+    const int len = lower_bound_u32(ix.ranks + base, (int)(end - base), (uint32_t)h.M);
+    for (int j = tid; j < len; j += WG) {
+      const Posting pst = ix.postings[base + j];
+      const int64_t id = pst.id;
+      const double s = pst.score;
+      if (h.excl_enabled && id == h.src_excl) continue;   // :90
+      if (id < h.earliest || id > h.latest) continue;     // :91
+      uint32_t slot;
+      bool fresh = false;
+      if (id == kEmptyKey) {
+        slot = S;
+        if (!s_special) { s_special = 1; fresh = true; }  // ids are unique within a list: one thread per round
+      } else {
+        slot = tweet_slot(mix64((uint64_t)id)) & (S - 1);
+        for (;;) {
+          unsigned long long old = atomicCAS((unsigned long long *)&keys[slot], (unsigned long long)kEmptyKey,
+                                             (unsigned long long)id);
+          if (old == (unsigned long long)kEmptyKey) { fresh = true; break; }
+          if (old == (unsigned long long)id) break;
+          slot = (slot + 1) & (S - 1);
+        }
+      }
+      double d0 = fresh ? 0.0 : dot[slot];  // getOrElse(tweetId, 0.0)
+      double n0 = fresh ? 0.0 : nsq[slot];
+      dot[slot] = d0 + s * w;               // :92-94
+      nsq[slot] = n0 + s * s;               // :95-96
+    }
+    __syncthreads();
+  }
+
+  // normalise + filter (:105-125); turn the table into (score_key, candidate flag)
+  int uniq = 0;
+  for (uint32_t i = tid; i <= S; i += WG) {
+    bool occ = (i < S) ? (keys[i] != kEmptyKey) : (s_special != 0);
+    double flag = 0.0;
+    if (occ) {
+      uniq++;
+      double sc = normalise(h.alg, dot[i], nsq[i], h.l2norm, h.lognorm);
+      if (sc >= h.min_score) {
+        dot[i] = bits_f64(score_key(sc));
+        flag = 1.0;
+      }
+    }
+    nsq[i] = flag;
+  }
+  if (uniq) atomicAdd(&s_unique, uniq);
+  __syncthreads();
+
+  TableSrc src{keys, dot, nsq, (int)S + 1};
+  uint64_t thi, tlo;
+  int n_valid;
+  const int kk = h.k < b.cap ? h.k : b.cap;
+  wg_select_threshold(src, kk, s_hist, s_ctl, thi, tlo, n_valid);
+  const int64_t obase = (int64_t)unit * b.cap;
+  for (int i = tid; i <= (int)S; i += WG) {
+    uint64_t hi, lo;
+    if (src.get(i, hi, lo) && key_ge(hi, lo, thi, tlo)) {
+      int o = atomicAdd(&s_cnt, 1);
+      if (o < b.cap) {
+        b.cand_key[obase + o] = hi;
+        b.cand_id[obase + o] = (i == (int)S) ? kEmptyKey : keys[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    b.cand_cnt[unit] = s_cnt < b.cap ? s_cnt : b.cap;
+    b.unit_unique[unit] = s_unique;
+    b.unit_flags[unit] = (n_valid > s_cnt) ? UNIT_TRUNCATED : UNIT_OK;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Merge: exact top-k over P unit lists of one query.
+// ---------------------------------------------------------------------------------------------
+struct UnitListSrc {
+  const uint64_t *cand_key;
+  const int64_t *cand_id;
+  const int32_t *cand_cnt;
+  int64_t unit0;  // first unit of the query
+  int P, cap;
+  __device__ int size() const { return P * cap; }
+  __device__ bool get(int i, uint64_t &hi, uint64_t &lo) const {
+    int u = i / cap, j = i - u * cap;
+    if (j >= cand_cnt[unit0 + u]) return false;
+    hi = cand_key[(unit0 + u) * cap + j];
+    lo = id_key(cand_id[(unit0 + u) * cap + j]);
+    return true;
+  }
+};
+
+template <class Src>
+__device__ void merge_select_sort_write(const Src &src, int k, int64_t *out_ids, double *out_scores, int32_t *out_count,
+                                        uint64_t *s_hi, uint64_t *s_lo, unsigned *s_hist, int *s_ctl, int *s_cnt,
+                                        int *s_sel_per_list /* may be NULL */, int cap_per_list) {
+  const int tid = threadIdx.x;
+  uint64_t thi, tlo;
+  int n_valid;
+  wg_select_threshold(src, k, s_hist, s_ctl, thi, tlo, n_valid);
+  if (tid == 0) *s_cnt = 0;
+  __syncthreads();
+  const int n = src.size();
+  for (int i = tid; i < n; i += WG) {
+    uint64_t hi, lo;
+    if (src.get(i, hi, lo) && key_ge(hi, lo, thi, tlo)) {
+      int o = atomicAdd(s_cnt, 1);
+      if (o < KMAX) { s_hi[o] = hi; s_lo[o] = lo; }
+      if (s_sel_per_list) atomicAdd(&s_sel_per_list[i / cap_per_list], 1);
+    }
+  }
+  __syncthreads();
+  int cnt = *s_cnt < KMAX ? *s_cnt : KMAX;
+  int np = next_pow2(cnt);
+  for (int i = cnt + tid; i < np; i += WG) { s_hi[i] = 0; s_lo[i] = 0; }
+  __syncthreads();
+  bitonic_sort_desc(s_hi, s_lo, np);
+  for (int i = tid; i < cnt; i += WG) {
+    out_ids[i] = key_id(s_lo[i]);
+    out_scores[i] = key_score(s_hi[i]);
+  }
+  if (tid == 0) *out_count = cnt;
+}
+
+__global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, const int32_t *query_list) {
+  __shared__ uint64_t s_hi[KMAX], s_lo[KMAX];
+  __shared__ unsigned s_hist[256];
+  __shared__ int s_ctl[4];
+  __shared__ int s_cnt;
+  __shared__ int s_sel[256];  // P <= 256
+
+  const int tid = threadIdx.x;
+  const int q = query_list ? query_list[blockIdx.x] : blockIdx.x;
+  const QueryHdr h = b.hdr[q];
+  for (int i = tid; i < 256; i += WG) s_sel[i] = 0;
+  __syncthreads();
+  UnitListSrc src{b.cand_key, b.cand_id, b.cand_cnt, (int64_t)q * ix.P, ix.P, b.cap};
+  merge_select_sort_write(src, h.k, b.out_ids + (int64_t)q * b.stride, b.out_scores + (int64_t)q * b.stride,
+                          b.out_counts + q, s_hi, s_lo, s_hist, s_ctl, &s_cnt, s_sel, b.cap);
+  __syncthreads();
+  // candidateScoresMap.size (:102) and the exactness check for truncated units
+  int msz = 0, inexact = 0;
+  const int cnt = s_cnt < KMAX ? s_cnt : KMAX;
+  for (int u = tid; u < ix.P; u += WG) {
+    int64_t unit = (int64_t)q * ix.P + u;
+    msz += b.unit_unique[unit];
+    uint32_t f = b.unit_flags[unit];
+    int emitted = b.cand_cnt[unit];
+    // a unit that withheld candidates is only harmless if one of its emitted entries lost
+    // (then everything it withheld is worse than the global k-th), or it emitted a full k.
+    if ((f & UNIT_TRUNCATED) && emitted < h.k && (s_sel[u] == emitted || cnt < h.k)) inexact = 1;
+  }
+  if (tid == 0) s_ctl[0] = 0, s_ctl[1] = 0;
+  __syncthreads();
+  if (msz) atomicAdd(&s_ctl[0], msz);
+  if (inexact) atomicOr(&s_ctl[1], 1);
+  __syncthreads();
+  if (tid == 0) {
+    b.out_map_sizes[q] = s_ctl[0];
+    if (s_ctl[1]) {
+      int o = atomicAdd(&b.status[1], 1);
+      b.status[2 + o] = q;  // status[2..] = list of inexact queries
+    }
+  }
+}
+
+// Per-shard results (already sorted rows) -> global top-k.
+struct ShardSrc {
+  const int64_t *ids;
+  const double *scores;
+  const int32_t *counts;
+  int n_shards, nq, stride, q;
+  __device__ int size() const { return n_shards * stride; }
+  __device__ bool get(int i, uint64_t &hi, uint64_t &lo) const {
+    int s = i / stride, j = i - s * stride;
+    if (j >= counts[(int64_t)s * nq + q]) return false;
+    int64_t o = ((int64_t)s * nq + q) * stride + j;
+    hi = score_key(scores[o]);
+    lo = id_key(ids[o]);
+    return true;
+  }
+};
+
+__global__ __launch_bounds__(WG) void merge_shards_kernel(int n_shards, int nq, int stride, const int64_t *ids,
+                                                         const double *scores, const int32_t *counts,
+                                                         const int32_t *map_sizes, const int32_t *k, int64_t *out_ids,
+                                                         double *out_scores, int32_t *out_counts,
+                                                         int32_t *out_map_sizes) {
+  __shared__ uint64_t s_hi[KMAX], s_lo[KMAX];
+  __shared__ unsigned s_hist[256];
+  __shared__ int s_ctl[4];
+  __shared__ int s_cnt;
+  const int q = blockIdx.x;
+  ShardSrc src{ids, scores, counts, n_shards, nq, stride, q};
+  int kk = k[q] < stride ? k[q] : stride;
+  merge_select_sort_write(src, kk, out_ids + (int64_t)q * stride, out_scores + (int64_t)q * stride, out_counts + q,
+                          s_hi, s_lo, s_hist, s_ctl, &s_cnt, nullptr, 1);
+  if (threadIdx.x == 0) {
+    int m = 0;
+    for (int s = 0; s < n_shards; s++) m += map_sizes[(int64_t)s * nq + q];
+    out_map_sizes[q] = m;
+  }
+}
+
+// Audit hook: out[i] = normalise(alg, dot[i], nsq[i], l2norm, lognorm) -- lets a test check the
+// device's fp64 division / sqrt / log bit-for-bit against the host.
+__global__ void debug_normalise_kernel(int alg, int n, const double *dot, const double *nsq, double l2norm,
+                                       double lognorm, double *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = normalise(alg, dot[i], nsq[i], l2norm, lognorm);
+}
+hipError_t launch_debug_normalise(int alg, int n, const double *dot, const double *nsq, double l2norm, double lognorm,
+                                  double *out, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(debug_normalise_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, alg, n, dot, nsq, l2norm,
+                     lognorm, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_unit_general(const IndexView &ix, const BatchView &b, const GeneralWs &ws, int n_units,
+                               hipStream_t stream) {
+  if (n_units <= 0) return hipSuccess;
+  hipLaunchKernelGGL(unit_general_kernel, dim3(n_units), dim3(WG), 0, stream, ix, b, ws);
+  return hipGetLastError();
+}
+hipError_t launch_merge(const IndexView &ix, const BatchView &b, const int32_t *query_list, int n_queries,
+                        hipStream_t stream) {
+  if (n_queries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(merge_kernel, dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
+  return hipGetLastError();
+}
+hipError_t launch_merge_shards(int n_shards, int nq, int stride, const int64_t *ids, const double *scores,
+                               const int32_t *counts, const int32_t *map_sizes, const int32_t *k, int64_t *out_ids,
+                               double *out_scores, int32_t *out_counts, int32_t *out_map_sizes, hipStream_t stream) {
+  if (nq <= 0) return hipSuccess;
+  hipLaunchKernelGGL(merge_shards_kernel, dim3(nq), dim3(WG), 0, stream, n_shards, nq, stride, ids, scores, counts,
+                     map_sizes, k, out_ids, out_scores, out_counts, out_map_sizes);
+  return hipGetLastError();
+}
+
+}  // namespace sann

@@ -1,0 +1,370 @@
+"""ctypes binding of include/simclusters_ann.h plus a thin mirror of the reference's operator
+interface, so that tests read like the Scala call sites.
+
+Reference interface mirrored (paths relative to /root/reference/):
+  simclusters-ann/server/src/main/scala/com/twitter/simclustersann/candidate_source/
+    ApproximateCosineSimilarity.scala:26-36        trait ApproximateCosineSimilarity.apply
+    SimClustersANNCandidateSource.scala:66-95      fetchCandidates (cluster choice + call)
+  simclusters-ann/thrift/src/main/thrift/simClustersAnn.thrift:18-37   SimClustersANNConfig, ScoringAlgorithm
+
+Everything here goes through libsimclusters_amd.so; there is no CPU fallback.  Loading fails
+loudly when the library has not been built (`make -C the-algorithm_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import enum
+import os
+from typing import Callable, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsimclusters_amd.so")
+
+
+class ScoringAlgorithm(enum.IntEnum):
+    """simClustersAnn.thrift:32-37"""
+
+    DotProduct = 1
+    CosineSimilarity = 2
+    LogCosineSimilarity = 3
+    CosineSimilarityNoSourceEmbeddingNormalization = 4
+
+
+class Variant(enum.IntEnum):
+    """Flag `approximate_cosine_similarity` (SimClustersANNCandidateSourceModule.scala:19-38)."""
+
+    original = 0
+    optimized = 1
+    experimental = 2
+
+
+class sann_config_t(C.Structure):
+    _fields_ = [
+        ("max_num_results", C.c_int32),
+        ("candidate_embedding_type", C.c_int32),
+        ("min_score", C.c_double),
+        ("max_top_tweets_per_cluster", C.c_int32),
+        ("max_scan_clusters", C.c_int32),
+        ("max_tweet_candidate_age_hours", C.c_int32),
+        ("min_tweet_candidate_age_hours", C.c_int32),
+        ("ann_algorithm", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class sann_index_options_t(C.Structure):
+    _fields_ = [("device", C.c_int32), ("n_partitions", C.c_int32), ("shard_id", C.c_int32), ("n_shards", C.c_int32)]
+
+
+class sann_index_info_t(C.Structure):
+    _fields_ = [
+        ("n_clusters", C.c_int64),
+        ("n_postings", C.c_int64),
+        ("n_postings_total", C.c_int64),
+        ("device_bytes", C.c_int64),
+        ("n_partitions", C.c_int32),
+        ("shard_id", C.c_int32),
+        ("n_shards", C.c_int32),
+        ("max_list_len", C.c_int32),
+    ]
+
+
+class sann_batch_stats_t(C.Structure):
+    _fields_ = [
+        ("postings_scanned", C.c_int64),
+        ("algorithmic_bytes", C.c_int64),
+        ("n_units", C.c_int32),
+        ("n_fallback_units", C.c_int32),
+        ("n_requeried", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+@dataclasses.dataclass
+class SimClustersANNConfig:
+    """simClustersAnn.thrift:18-27.  Defaults = cr-mixer's DefaultConfig
+    (cr-mixer/server/src/main/scala/com/twitter/cr_mixer/config/SimClustersANNConfig.scala:33-42)."""
+
+    maxNumResults: int = 200
+    minScore: float = 0.0
+    candidateEmbeddingType: int = 0
+    maxTopTweetsPerCluster: int = 800
+    maxScanClusters: int = 50
+    maxTweetCandidateAgeHours: int = 24
+    minTweetCandidateAgeHours: int = 0
+    annAlgorithm: ScoringAlgorithm = ScoringAlgorithm.CosineSimilarity
+
+    def to_c(self) -> sann_config_t:
+        return sann_config_t(
+            int(self.maxNumResults),
+            int(self.candidateEmbeddingType),
+            float(self.minScore),
+            int(self.maxTopTweetsPerCluster),
+            int(self.maxScanClusters),
+            int(self.maxTweetCandidateAgeHours),
+            int(self.minTweetCandidateAgeHours),
+            int(self.annAlgorithm),
+            0,
+        )
+
+
+class SannError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"simclusters_amd error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+_PROTOS = {
+    "sann_last_error": (C.c_char_p, []),
+    "sann_version": (C.c_char_p, []),
+    "sann_index_build": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "sann_index_info": (C.c_int, [C.c_void_p, C.POINTER(sann_index_info_t)]),
+    "sann_index_get_list": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "sann_index_destroy": (C.c_int, [C.c_void_p]),
+    "sann_batch_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "sann_batch_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sann_batch_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sann_batch_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sann_batch_device_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
+    "sann_batch_device_k": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "sann_batch_stats": (C.c_int, [C.c_void_p, C.POINTER(sann_batch_stats_t)]),
+    "sann_batch_destroy": (C.c_int, [C.c_void_p]),
+    "sann_get_tweet_candidates": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sann_debug_normalise": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
+    "sann_merge_shards": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+
+def exported_symbols() -> List[str]:
+    """Every symbol include/simclusters_ann.h declares."""
+    return list(_PROTOS)
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libsimclusters_amd.so and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(
+            f"{p} is missing: build the HIP extension first (make -C the-algorithm_amd/csrc, or "
+            "python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback."
+        )
+    lib = C.CDLL(p)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise SannError(rc, load_library().sann_last_error().decode())
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class ClusterTweetIndex:
+    """Device-resident `ReadableStore[ClusterId, Seq[(TweetId, Double)]]`
+    (ClusterTweetIndexProviderModule.scala:34-94): lists already filtered > 0, sorted by score
+    descending and capped, exactly as the reference store returns them."""
+
+    def __init__(self, cluster_ids, list_offsets, tweet_ids, scores, *, device: int = 0, n_partitions: int = 0,
+                 shard_id: int = 0, n_shards: int = 1):
+        lib = load_library()
+        self.cluster_ids = np.ascontiguousarray(cluster_ids, dtype=np.int32)
+        self.list_offsets = np.ascontiguousarray(list_offsets, dtype=np.int64)
+        tweet_ids = np.ascontiguousarray(tweet_ids, dtype=np.int64)
+        scores = np.ascontiguousarray(scores, dtype=np.float64)
+        opts = sann_index_options_t(device, n_partitions, shard_id, n_shards)
+        h = C.c_void_p()
+        _check(lib.sann_index_build(C.byref(opts), len(self.cluster_ids), _ptr(self.cluster_ids), _ptr(self.list_offsets),
+                                    _ptr(tweet_ids), _ptr(scores), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    @classmethod
+    def from_map(cls, cluster_tweets: Mapping[int, Sequence[Tuple[int, float]]], **kw) -> "ClusterTweetIndex":
+        cids = sorted(cluster_tweets)
+        offs = [0]
+        tids: List[int] = []
+        scs: List[float] = []
+        for c in cids:
+            for t, s in cluster_tweets[c]:
+                tids.append(t)
+                scs.append(s)
+            offs.append(len(tids))
+        return cls(np.array(cids, np.int32), np.array(offs, np.int64), np.array(tids, np.int64), np.array(scs, np.float64), **kw)
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    def info(self) -> sann_index_info_t:
+        i = sann_index_info_t()
+        _check(load_library().sann_index_info(self._h, C.byref(i)))
+        return i
+
+    def get_list(self, cluster_id: int):
+        lib = load_library()
+        n = C.c_int64()
+        _check(lib.sann_index_get_list(self._h, cluster_id, 0, None, None, None, C.byref(n)))
+        t = np.empty(n.value, np.int64)
+        s = np.empty(n.value, np.float64)
+        r = np.empty(n.value, np.int32)
+        if n.value:
+            _check(lib.sann_index_get_list(self._h, cluster_id, n.value, _ptr(t), _ptr(s), _ptr(r), C.byref(n)))
+        return t, s, r
+
+    def close(self):
+        if self._h:
+            load_library().sann_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _csr(rows: Sequence[Sequence], dtype) -> Tuple[np.ndarray, np.ndarray]:
+    offs = np.zeros(len(rows) + 1, np.int64)
+    for i, r in enumerate(rows):
+        offs[i + 1] = offs[i] + len(r)
+    flat = np.empty(int(offs[-1]), dtype)
+    for i, r in enumerate(rows):
+        flat[offs[i]:offs[i + 1]] = r
+    return offs, flat
+
+
+class QueryBatch:
+    """A prepared batch (sann_batch_t): create once, run many times."""
+
+    def __init__(self, index: ClusterTweetIndex, emb_offsets, emb_cluster_ids, emb_scores, configs, *, now_ms: int,
+                 variant: Variant = Variant.original, source_tweet_ids=None, has_source_tweet=None,
+                 scan_offsets=None, scan_cluster_ids=None):
+        lib = load_library()
+        self.index = index
+        self.nq = len(emb_offsets) - 1
+        self._keep = [
+            np.ascontiguousarray(emb_offsets, np.int64),
+            np.ascontiguousarray(emb_cluster_ids, np.int32),
+            np.ascontiguousarray(emb_scores, np.float64),
+            None if source_tweet_ids is None else np.ascontiguousarray(source_tweet_ids, np.int64),
+            None if has_source_tweet is None else np.ascontiguousarray(has_source_tweet, np.uint8),
+            None if scan_offsets is None else np.ascontiguousarray(scan_offsets, np.int64),
+            None if scan_cluster_ids is None else np.ascontiguousarray(scan_cluster_ids, np.int32),
+        ]
+        if isinstance(configs, SimClustersANNConfig):
+            configs = [configs]
+        self.configs = list(configs)
+        carr = (sann_config_t * len(self.configs))(*[c.to_c() for c in self.configs])
+        h = C.c_void_p()
+        k = self._keep
+        _check(lib.sann_batch_create(index.handle, int(variant), int(now_ms), self.nq, _ptr(k[0]), _ptr(k[1]), _ptr(k[2]),
+                                     _ptr(k[3]), _ptr(k[4]), C.cast(carr, C.c_void_p), len(self.configs), _ptr(k[5]),
+                                     _ptr(k[6]), C.byref(h)))
+        self._h = h
+        self.stride = max(1, max(min(max(c.maxNumResults, 0), 1000) for c in self.configs))
+
+    def run(self, stream: int = 0):
+        _check(load_library().sann_batch_run(self._h, C.c_void_p(stream)))
+
+    def finish(self, stream: int = 0):
+        _check(load_library().sann_batch_finish(self._h, C.c_void_p(stream)))
+
+    def results(self):
+        ids = np.zeros((self.nq, self.stride), np.int64)
+        scores = np.zeros((self.nq, self.stride), np.float64)
+        counts = np.zeros(self.nq, np.int32)
+        msz = np.zeros(self.nq, np.int32)
+        _check(load_library().sann_batch_results(self._h, _ptr(ids), _ptr(scores), self.stride, _ptr(counts), _ptr(msz)))
+        return ids, scores, counts, msz
+
+    def device_results(self):
+        p = [C.c_void_p() for _ in range(4)]
+        st = C.c_int32()
+        _check(load_library().sann_batch_device_results(self._h, *[C.byref(x) for x in p], C.byref(st)))
+        return [x.value for x in p], st.value
+
+    def device_k(self) -> int:
+        p = C.c_void_p()
+        _check(load_library().sann_batch_device_k(self._h, C.byref(p)))
+        return p.value
+
+    def stats(self) -> sann_batch_stats_t:
+        s = sann_batch_stats_t()
+        _check(load_library().sann_batch_stats(self._h, C.byref(s)))
+        return s
+
+    def close(self):
+        if self._h:
+            load_library().sann_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ApproximateCosineSimilarity:
+    """The `gpu` value of flag approximate_cosine_similarity: same signature as
+    `trait ApproximateCosineSimilarity.apply` (ApproximateCosineSimilarity.scala:26-36), with the
+    cluster -> tweets map held on the device by handle instead of passed by value.
+
+    sourceEmbedding         iterable of (clusterId, score)
+    sourceEmbeddingId       tweet id when the source is InternalId.TweetId, else None
+    clusterTweetsMapKeys    optional explicit key order of clusterTweetsMap (None = fetchCandidates)
+    """
+
+    def __init__(self, index: ClusterTweetIndex, variant: Variant = Variant.original, now_ms: Optional[int] = None):
+        self.index = index
+        self.variant = variant
+        self.now_ms = now_ms
+
+    def apply(self, sourceEmbedding: Iterable[Tuple[int, float]], sourceEmbeddingId: Optional[int],
+              config: SimClustersANNConfig, candidateScoresStat: Callable[[int], None] = lambda _n: None,
+              clusterTweetsMapKeys: Optional[Sequence[int]] = None, now_ms: Optional[int] = None) -> List[Tuple[int, float]]:
+        res = self.apply_batch([list(sourceEmbedding)], [sourceEmbeddingId], config, candidateScoresStat,
+                               None if clusterTweetsMapKeys is None else [clusterTweetsMapKeys], now_ms)
+        return res[0]
+
+    def apply_batch(self, embeddings, source_ids, config, candidateScoresStat=lambda _n: None, scan_keys=None,
+                    now_ms: Optional[int] = None) -> List[List[Tuple[int, float]]]:
+        import time
+
+        now = now_ms if now_ms is not None else (self.now_ms if self.now_ms is not None else int(time.time() * 1000))
+        eo, ec = _csr([[c for c, _ in e] for e in embeddings], np.int32)
+        _, es = _csr([[s for _, s in e] for e in embeddings], np.float64)
+        src = np.array([0 if s is None else s for s in source_ids], np.int64)
+        has = np.array([0 if s is None else 1 for s in source_ids], np.uint8)
+        so = sc = None
+        if scan_keys is not None:
+            so, sc = _csr(scan_keys, np.int32)
+        qb = QueryBatch(self.index, eo, ec, es, config, now_ms=now, variant=self.variant, source_tweet_ids=src,
+                        has_source_tweet=has, scan_offsets=so, scan_cluster_ids=sc)
+        try:
+            qb.run()
+            qb.finish()
+            ids, scores, counts, msz = qb.results()
+        finally:
+            qb.close()
+        out = []
+        for q in range(len(embeddings)):
+            candidateScoresStat(int(msz[q]))
+            out.append([(int(ids[q, i]), float(scores[q, i])) for i in range(counts[q])])
+        return out
