@@ -274,7 +274,8 @@ def test_device_fp64_division_sqrt_log_are_bit_exact(pkg, oracle):
             ref = dot / np.sqrt(nsq)
         else:
             lg = np.array([L.oracle_strict_log(float(1 + x)) for x in nsq[:50000]])
-            ref = dot[:50000] / ln / lg
+            with np.errstate(divide="ignore"):
+                ref = dot[:50000] / ln / lg
         m = len(ref)
         bad = np.nonzero(out[:m].view(np.int64) != np.asarray(ref).view(np.int64))[0]
         assert len(bad) == 0, (alg, len(bad), out[bad[:3]], np.asarray(ref)[bad[:3]])

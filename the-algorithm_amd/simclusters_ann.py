@@ -16,6 +16,7 @@ import ctypes as C
 import dataclasses
 import enum
 import os
+import sys
 from typing import Callable, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -151,6 +152,16 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # One HIP runtime per process.  torch bundles its own libamdhip64.so.7 and always loads it
+    # (RPATH $ORIGIN); ours is found by soname, so it binds to whichever copy is loaded first.
+    # If torch will be used in this process it therefore has to be imported BEFORE the dlopen
+    # below, or torch later fails with "No HIP GPUs are available" (two ROCr instances).
+    # Torch-free processes (bench.py at N=1, a JVM) set SANN_NO_TORCH=1 and get the system runtime.
+    if os.environ.get("SANN_NO_TORCH") != "1" and "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} is missing: build the HIP extension first (make -C the-algorithm_amd/csrc, or "
