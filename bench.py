@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- candidates/sec of batched SimClusters-ANN getTweetCandidates on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic user queries whose prepared
+form (embeddings, cluster rows, weights) and whose index are already resident in HBM:
+gather posting lists -> ordered fp64 accumulate -> normalise -> filter -> exact top-k, i.e.
+ApproximateCosineSimilarity.apply (reference simclusters-ann/.../candidate_source/
+ApproximateCosineSimilarity.scala:57-128) for every query of the batch.
+
+N = 1   workload = BASELINE.json configs[2]: 1024 concurrent user queries, one GPU.
+N > 1   the corpus is tweet-hash sharded over the N ranks (one process per GPU); every rank
+        answers the whole batch (1024*N queries) on its shard, per-shard top-k lists are
+        all-gathered over RCCL and merged exactly on every rank (ComposedQueryable pattern,
+        reference ann/.../common/ShardApi.scala:71-87).  Per-GPU posting work is constant in N:
+        "scaling": "weak".
+
+Prints ONE JSON line on rank 0 (see the task contract) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tweets", type=int, default=int(os.environ.get("SANN_BENCH_TWEETS", 1_000_000)))
+    ap.add_argument("--queries-per-gpu", type=int, default=1024)
+    ap.add_argument("--alg", default="cosine", choices=["cosine", "logcosine", "dot"])
+    ap.add_argument("--partitions", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-queries", type=int, default=16, help="queries checked bit-for-bit against the oracle")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        os.environ.setdefault("SANN_NO_TORCH", "1")  # torch-free: system HIP runtime, profiler-friendly
+
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+
+    pkg = ge.load_package()
+    lib = pkg.load_library()
+    SA = pkg.ScoringAlgorithm
+    alg = {"cosine": SA.CosineSimilarity, "logcosine": SA.LogCosineSimilarity, "dot": SA.DotProduct}[args.alg]
+
+    # ---- synthetic corpus + queries; identical on every rank ---------------------
+    t0 = time.time()
+    co = pkg.corpus.make_corpus(args.tweets)
+    nq = args.queries_per_gpu * world
+    offs, cids, scs = pkg.corpus.make_queries(nq)
+    t_corpus = time.time() - t0
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, device=local_rank,
+                                  n_partitions=args.partitions, shard_id=rank, n_shards=world)
+    # cr-mixer default config with maxNumResults = 400
+    cfg = pkg.SimClustersANNConfig(maxNumResults=400, minScore=0.0, maxTopTweetsPerCluster=800, maxScanClusters=50,
+                                   maxTweetCandidateAgeHours=24, minTweetCandidateAgeHours=0, annAlgorithm=alg)
+    qb = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=co.now_ms)
+    stride = qb.stride
+    stream = 0
+
+    # ---- multi-GPU plumbing: one packed buffer per rank -> one all_gather -> exact merge ------
+    if world > 1:
+        stream = torch.cuda.current_stream().cuda_stream
+        L = 2 * nq * stride + nq  # int64 words: ids | score bits | (counts int32[nq], map sizes int32[nq])
+        mine = torch.zeros(L, dtype=torch.int64, device="cuda")
+        gathered = torch.zeros(world * L, dtype=torch.int64, device="cuda")
+        base = mine.data_ptr()
+        qb.bind_outputs(base, base + nq * stride * 8, base + 2 * nq * stride * 8, base + 2 * nq * stride * 8 + nq * 4)
+        g = gathered.data_ptr()
+        out_ids = torch.zeros((nq, stride), dtype=torch.int64, device="cuda")
+        out_sc = torch.zeros((nq, stride), dtype=torch.float64, device="cuda")
+        out_cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+        out_msz = torch.zeros(nq, dtype=torch.int32, device="cuda")
+        d_k = qb.device_k()
+
+    def step():
+        qb.run(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, mine)
+            rc = lib.sann_merge_shards(local_rank, ctypes.c_void_p(stream), world, nq, stride, L * 8, g,
+                                       g + nq * stride * 8, g + 2 * nq * stride * 8, g + 2 * nq * stride * 8 + nq * 4,
+                                       d_k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr())
+            assert rc == 0, lib.sann_last_error()
+        qb.finish(stream)  # waits for the stream; re-runs whatever the fast path flagged
+
+    def sync():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        else:
+            assert lib.sann_device_synchronize(local_rank) == 0
+
+    for _ in range(args.warmup):
+        step()
+    qb.set_profiling(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    unit_ms, merge_ms, n_timed = qb.kernel_times()
+    qb.set_profiling(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- results of the last step -------------------------------------------------------------
+    if world > 1:
+        torch.cuda.synchronize()
+        ids, scores, counts, msz = out_ids.cpu().numpy(), out_sc.cpu().numpy(), out_cnt.cpu().numpy(), out_msz.cpu().numpy()
+    else:
+        ids, scores, counts, msz = qb.results()
+    st = qb.stats()
+    candidates_per_step = int(counts.sum())
+    value = candidates_per_step * args.steps / elapsed
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- parity spot check against the oracle (outside the timed region) -----------------------
+    oracle = ge.load_oracle()
+    n_check = min(args.check_queries, nq)
+    exact = 0
+    for q in range(n_check):
+        o_ids, o_sc, o_msz = oracle.sann_query(cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]], None, cfg, co.now_ms,
+                                               co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores)
+        ok = (counts[q] == len(o_ids) and msz[q] == o_msz and np.array_equal(ids[q, :counts[q]], o_ids)
+              and np.array_equal(scores[q, :counts[q]].view(np.int64), o_sc.view(np.int64)))
+        exact += int(ok)
+    recall_parity = exact / max(n_check, 1)
+
+    # ---- CPU baseline: the C restatement of the Scala path on the host cores, bounded sample ---
+    cpu = None
+    if not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        o_i = np.zeros((nq, 1000), np.int64)
+        o_s = np.zeros((nq, 1000), np.float64)
+        o_c = np.zeros(nq, np.int32)
+        probe = min(nq, 4 * cores)
+        sec = oracle.baseline_run(0, cores, offs[:probe + 1], cids, scs, cfg, co.now_ms, co.cluster_ids, co.list_offsets,
+                                  co.tweet_ids, co.scores, o_i, o_s, o_c)
+        n_s = int(min(nq, max(probe, args.cpu_seconds / max(sec / probe, 1e-9))))
+        sec = oracle.baseline_run(0, cores, offs[:n_s + 1], cids, scs, cfg, co.now_ms, co.cluster_ids, co.list_offsets,
+                                  co.tweet_ids, co.scores, o_i, o_s, o_c)
+        cpu = {"value": float(o_c[:n_s].sum() / sec), "unit": "candidates/sec", "cores": cores, "kind": "port",
+               "sample": f"{n_s} of the {nq} queries, 'original' semantics (two-map accumulate + full sort), "
+                         f"{sec:.2f} s wall; C restatement of the Scala CPU path, not the JVM"}
+
+    # ---- roofline of the dominant kernel (unit kernel: gather + accumulate + select) -----------
+    # algorithmic bytes per launch: sum_q P_q*16 + n*12 + k_out*16
+    alg_bytes = int(st.algorithmic_bytes) + candidates_per_step * 16 if world == 1 else int(st.algorithmic_bytes) + int(counts.sum()) * 16
+    unit_avg_ms = unit_ms / max(n_timed, 1)
+    achieved = alg_bytes / (unit_avg_ms * 1e-3) / 1e9 if unit_avg_ms > 0 else 0.0
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "kernel": "sann unit kernel (gather+accumulate+select)", "kernel_avg_ms": unit_avg_ms,
+            "merge_kernel_avg_ms": merge_ms / max(n_timed, 1), "algorithmic_bytes_per_launch": alg_bytes}
+
+    line = {
+        "metric": "candidates/sec + recall@400, 100M-tweet SimClusters-ANN @1/2/4/8 GPU",
+        "value": value,
+        "unit": "candidates/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"batched simclusters-ann, {nq} concurrent user queries, {args.tweets} tweets x 144428 clusters, "
+                               f"top-400, N=50 M=800 {args.alg}, {'1xMI355X' if world == 1 else f'{world}xMI355X tweet-hash shards + RCCL all-gather merge'}",
+                   "queries": nq, "tweets": args.tweets, "clusters": 144428, "k": 400, "max_scan_clusters": 50,
+                   "max_top_tweets_per_cluster": 800, "algorithm": args.alg, "index_cap": 2000,
+                   "partitions": index.info().n_partitions, "sharding": "none" if world == 1 else "tweet-hash"},
+        "queries_per_sec": nq * args.steps / elapsed,
+        "postings_per_sec": int(st.postings_scanned) * args.steps / elapsed,
+        "recall_at_400_parity": recall_parity,
+        "parity_checked_queries": n_check,
+        "fallback_units": int(st.n_fallback_units),
+        "roofline": roof,
+        "cpu_baseline": cpu,
+        "corpus_build_s": t_corpus,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

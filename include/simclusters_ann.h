@@ -162,6 +162,13 @@ int sann_batch_results(sann_batch_t *batch, int64_t *out_ids, double *out_scores
 int sann_batch_device_results(sann_batch_t *batch, void **d_ids, void **d_scores, void **d_counts,
                               void **d_map_sizes, int32_t *stride);
 int sann_batch_stats(sann_batch_t *batch, sann_batch_stats_t *stats);
+/* Measurement: when enabled, sann_batch_run brackets the unit (gather + accumulate + select)
+ * kernel(s) and the merge kernel with HIP events on the launch stream; sann_batch_finish adds
+ * the elapsed times to running totals.  Resets the totals. */
+int sann_batch_set_profiling(sann_batch_t *batch, int32_t enable);
+int sann_batch_kernel_times(sann_batch_t *batch, double *unit_ms_total, double *merge_ms_total, int32_t *n_runs);
+/* hipDeviceSynchronize on `device` (for callers that do not link the HIP runtime themselves). */
+int sann_device_synchronize(int32_t device);
 int sann_batch_destroy(sann_batch_t *batch);
 
 /* One call = create + run + finish + results + destroy: the shape a JNI stub binds. */
@@ -181,9 +188,17 @@ int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_
  * Output rows have stride `stride`; d_out_map_sizes is the sum over shards.
  */
 int sann_merge_shards(int32_t device, void *hip_stream, int32_t n_shards, int32_t nq, int32_t stride,
+                      int64_t shard_pitch_bytes /* 0 = each array tightly packed shard-major; else every
+                      array of shard s starts s*pitch bytes after shard 0's (one packed all-gather) */,
                       const void *d_ids, const void *d_scores, const void *d_counts, const void *d_map_sizes,
                       const void *d_k /* int32[nq]: min(maxNumResults,1000) per query */, void *d_out_ids,
                       void *d_out_scores, void *d_out_counts, void *d_out_map_sizes);
+
+/* Make the merge kernel write the final results into caller-owned device buffers (e.g. torch
+ * tensors that feed an all-gather) instead of the batch's own; pass four NULLs to unbind.
+ * Sizes: int64[nq*stride], double[nq*stride], int32[nq], int32[nq], stride as reported by
+ * sann_batch_device_results. */
+int sann_batch_bind_outputs(sann_batch_t *batch, void *d_ids, void *d_scores, void *d_counts, void *d_map_sizes);
 
 /* Device pointer to int32[nq] holding min(max(maxNumResults,0),1000) per query. */
 int sann_batch_device_k(sann_batch_t *batch, void **d_k);

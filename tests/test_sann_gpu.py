@@ -236,7 +236,7 @@ def test_tweet_hash_shards_merge_exactly(pkg, oracle, small):
     o_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
     o_msz = torch.zeros(nq, dtype=torch.int32, device=dev)
     lib = pkg.load_library()
-    rc = lib.sann_merge_shards(0, None, S, nq, stride, g_ids.data_ptr(), g_sc.data_ptr(), g_cnt.data_ptr(),
+    rc = lib.sann_merge_shards(0, None, S, nq, stride, 0, g_ids.data_ptr(), g_sc.data_ptr(), g_cnt.data_ptr(),
                                g_msz.data_ptr(), batches[0][1].device_k(), o_ids.data_ptr(), o_sc.data_ptr(),
                                o_cnt.data_ptr(), o_msz.data_ptr())
     assert rc == 0, lib.sann_last_error()
@@ -279,3 +279,92 @@ def test_device_fp64_division_sqrt_log_are_bit_exact(pkg, oracle):
         m = len(ref)
         bad = np.nonzero(out[:m].view(np.int64) != np.asarray(ref).view(np.int64))[0]
         assert len(bad) == 0, (alg, len(bad), out[bad[:3]], np.asarray(ref)[bad[:3]])
+
+
+def _mix64(x):
+    m = (1 << 64) - 1
+    x &= m
+    x ^= x >> 33
+    x = (x * 0xff51afd7ed558ccd) & m
+    x ^= x >> 33
+    x = (x * 0xc4ceb9fe1a85ec53) & m
+    x ^= x >> 33
+    return x
+
+
+def test_forced_general_path_matches(pkg, oracle, small, monkeypatch):
+    co, offs, cids, scs = small
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=8)
+    cfg = pkg.SimClustersANNConfig(maxNumResults=400, maxTopTweetsPerCluster=300)
+    monkeypatch.setenv("SANN_FORCE_GENERAL", "1")
+    out, st = run_batch(pkg, index, co, offs, cids, scs, cfg)
+    monkeypatch.delenv("SANN_FORCE_GENERAL")
+    check_against_oracle(pkg, oracle, co, offs, cids, scs, cfg, out)
+    out2, st2 = run_batch(pkg, index, co, offs, cids, scs, cfg)
+    for a, b in zip(out, out2):
+        assert np.array_equal(a, b)
+    index.close()
+
+
+def test_fast_path_falls_back_when_units_do_not_fit(pkg, oracle, small):
+    """P = 1: a unit is a whole query (thousands of postings): the LDS path flags overflow and the
+    general kernel settles it; results stay exact and the stats say so."""
+    co, offs, cids, scs = small
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=1)
+    cfg = pkg.SimClustersANNConfig(maxNumResults=400, maxTopTweetsPerCluster=400)
+    out, st = run_batch(pkg, index, co, offs, cids, scs, cfg)
+    check_against_oracle(pkg, oracle, co, offs, cids, scs, cfg, out)
+    assert st.n_fallback_units > 0
+    index.close()
+
+
+def test_skewed_partition_forces_requery(pkg, oracle):
+    """All high scorers hash to ONE partition: that unit truncates its list, the merge cannot
+    prove the top-k exact, the query is re-run on the general path.  Still bit-exact."""
+    P = 32
+    rng = np.random.default_rng(31)
+    hot, cold = [], []
+    x = 1 << 40
+    while len(hot) < 600 or len(cold) < 3000:
+        x += int(rng.integers(1, 1000))
+        (hot if (_mix64(x) & (P - 1)) == 5 else cold).append(x)
+    hot, cold = hot[:600], cold[:3000]
+    # DotProduct scoring: cluster 1 (weight 10) lists only partition-5 tweets with the highest scores
+    lists = {1: [(t, 5.0 - 0.001 * i) for i, t in enumerate(hot)],
+             2: [(t, 1.0 - 0.0001 * i) for i, t in enumerate(cold[:1500])],
+             3: [(t, 0.9 - 0.0001 * i) for i, t in enumerate(cold[1500:])]}
+    index = pkg.ClusterTweetIndex.from_map(lists, n_partitions=P)
+    cids_c = np.array([1, 2, 3], np.int32)
+    offs_c = np.array([0, 600, 2100, 3600], np.int64)
+    t_c = np.array([t for c in (1, 2, 3) for t, _ in lists[c]], np.int64)
+    s_c = np.array([s for c in (1, 2, 3) for _, s in lists[c]], np.float64)
+
+    class Co:
+        now_ms = 1_700_000_000_000
+        cluster_ids, list_offsets, tweet_ids, scores = cids_c, offs_c, t_c, s_c
+
+    offs = np.array([0, 3], np.int64)
+    cids = np.array([1, 2, 3], np.int32)
+    scs = np.array([10.0, 1.0, 1.0])
+    cfg = pkg.SimClustersANNConfig(maxNumResults=400, maxTopTweetsPerCluster=2000, maxTweetCandidateAgeHours=175200,
+                                   annAlgorithm=pkg.ScoringAlgorithm.DotProduct)
+    out, st = run_batch(pkg, index, Co, offs, cids, scs, cfg)
+    check_against_oracle(pkg, oracle, Co, offs, cids, scs, cfg, out)
+    assert set(out[0][0, :400].tolist()) <= set(hot)
+    assert st.n_requeried == 1 and st.n_fallback_units == P
+    index.close()
+
+
+def test_many_scan_clusters_overflow_to_general(pkg, oracle, small):
+    """More scanned clusters than the fast path's descriptor table (128) -> general path."""
+    co, offs, cids, scs = small
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=16)
+    rng = np.random.default_rng(2)
+    e_c = rng.choice(co.cluster_ids, size=300, replace=False).astype(np.int32)
+    e_s = np.exp(rng.normal(0, 1, 300))
+    e_offs = np.array([0, 300], np.int64)
+    cfg = pkg.SimClustersANNConfig(maxNumResults=400, maxTopTweetsPerCluster=50, maxScanClusters=300)
+    out, st = run_batch(pkg, index, co, e_offs, e_c, e_s, cfg)
+    check_against_oracle(pkg, oracle, co, e_offs, e_c, e_s, cfg, out)
+    assert st.n_fallback_units == 16
+    index.close()

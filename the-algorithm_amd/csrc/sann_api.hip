@@ -107,39 +107,60 @@ struct sann_batch {
   std::vector<int32_t> h_scan_row;
   std::vector<double> h_scan_w;
   std::vector<int32_t> h_k;
-  DevBuf hdr, scan_row, scan_w, d_k;
-  DevBuf cand_key, cand_id, cand_cnt, unit_unique, unit_flags, status, overflow_units;
+  DevBuf hdr, scan_row, scan_w, scan_q, desc, d_k;
+  std::vector<int32_t> h_scan_q;
+  DevBuf cand_key, cand_id, cand_cnt, unit_unique, unit_flags, unit_fb, unit_thr, status, overflow_units;
   DevBuf out_ids, out_scores, out_counts, out_map_sizes;
-  // general path workspace
-  DevBuf g_units, g_off, g_slots, g_keys, g_dot, g_nsq;
-  int g_n = 0;
-  int64_t g_entries = 0;
+  // caller-bound output buffers (NULL = the batch's own)
+  void *bound_ids = nullptr, *bound_scores = nullptr, *bound_counts = nullptr, *bound_map_sizes = nullptr;
+  // general path: workspace and candidate lists for the units it (re)runs, grown on demand
+  std::vector<uint32_t> unit_bound;  // upper bound on the postings a unit can scan
+  int cap2 = 1;
+  DevBuf cand_key2, cand_id2, g_units, g_off, g_slots, g_keys, g_dot, g_nsq, g_queries;
+  int g_cap_units = 0;        // units the g_* / cand_*2 buffers can hold
+  int64_t g_cap_entries = 0;  // table entries the g_keys/dot/nsq buffers can hold
   int32_t *h_status = nullptr;  // pinned: [0] overflow units, [1] inexact queries
   bool use_fast = false;
   FastParams fast{};
   sann_batch_stats_t stats{};
   bool ran = false;
+  // optional HIP-event timing of the kernels, on the stream they are launched on
+  bool profiling = false;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  bool ev_pending = false;
+  double unit_ms_total = 0.0, merge_ms_total = 0.0;
+  int timed_runs = 0;
 
-  ~sann_batch() { if (h_status) (void)hipHostFree(h_status); }
+  ~sann_batch() {
+    if (h_status) (void)hipHostFree(h_status);
+    for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+  }
 
   BatchView view() const {
     BatchView b;
     b.hdr = hdr.as<QueryHdr>();
     b.scan_row = scan_row.as<int32_t>();
     b.scan_w = scan_w.as<double>();
+    b.scan_q = scan_q.as<int32_t>();
+    b.desc = desc.as<uint32_t>();
     b.nq = nq;
     b.cap = cap;
+    b.cap2 = cap2;
     b.cand_key = cand_key.as<uint64_t>();
     b.cand_id = cand_id.as<int64_t>();
+    b.cand_key2 = cand_key2.as<uint64_t>();
+    b.cand_id2 = cand_id2.as<int64_t>();
+    b.unit_fb = unit_fb.as<int32_t>();
+    b.unit_thr = unit_thr.as<uint64_t>();
     b.cand_cnt = cand_cnt.as<int32_t>();
     b.unit_unique = unit_unique.as<int32_t>();
     b.unit_flags = unit_flags.as<uint32_t>();
     b.status = status.as<int32_t>();
     b.overflow_units = overflow_units.as<int32_t>();
-    b.out_ids = out_ids.as<int64_t>();
-    b.out_scores = out_scores.as<double>();
-    b.out_counts = out_counts.as<int32_t>();
-    b.out_map_sizes = out_map_sizes.as<int32_t>();
+    b.out_ids = bound_ids ? (int64_t *)bound_ids : out_ids.as<int64_t>();
+    b.out_scores = bound_scores ? (double *)bound_scores : out_scores.as<double>();
+    b.out_counts = bound_counts ? (int32_t *)bound_counts : out_counts.as<int32_t>();
+    b.out_map_sizes = bound_map_sizes ? (int32_t *)bound_map_sizes : out_map_sizes.as<int32_t>();
     b.stride = stride;
     return b;
   }
@@ -329,6 +350,7 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
   int kmax = 1;
   int64_t postings_scanned = 0, alg_bytes = 0;
   std::vector<uint64_t> unit_bound((size_t)b->n_units, 0);
+  std::vector<double> unit_est((size_t)b->n_units, 0.0);  // expected postings with rank < M
 
   for (int32_t q = 0; q < nq; q++) {
     const sann_config_t &cfg = configs[n_configs == 1 ? 0 : q];
@@ -396,15 +418,19 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
       if (row < 0) continue;  // None in clusterTweetsMap
       b->h_scan_row.push_back(row);
       b->h_scan_w.push_back(w);
+      b->h_scan_q.push_back(q);
       uint64_t bound_sum = 0;
+      const uint64_t whole = ix->h_sub_offsets[(size_t)(row + 1) * ix->P] - ix->h_sub_offsets[(size_t)row * ix->P];
+      // share of the list with rank < M, as if this shard held 1/n_shards of every list
+      const double frac = whole == 0 ? 0.0 : std::min(1.0, (double)h.M / ((double)whole * ix->n_shards));
       for (int p = 0; p < ix->P; p++) {
         uint64_t len = ix->h_sub_offsets[(size_t)row * ix->P + p + 1] - ix->h_sub_offsets[(size_t)row * ix->P + p];
         uint64_t lim = std::min<uint64_t>(len, (uint64_t)h.M);
         unit_bound[(size_t)q * ix->P + p] += lim;
+        unit_est[(size_t)q * ix->P + p] += (double)len * frac;
         bound_sum += lim;
       }
       // exact when this shard holds whole lists: min(len_c, M) postings have rank < M
-      uint64_t whole = ix->h_sub_offsets[(size_t)(row + 1) * ix->P] - ix->h_sub_offsets[(size_t)row * ix->P];
       postings_scanned += (int64_t)(ix->n_shards == 1 ? std::min<uint64_t>(whole, (uint64_t)h.M) : bound_sum);
     }
     h.n_scan = (int32_t)b->h_scan_row.size() - h.scan_begin;
@@ -416,20 +442,51 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
   b->stats.algorithmic_bytes = alg_bytes + postings_scanned * 16;
   b->stats.n_units = b->n_units;
 
-  b->cap = kmax;
   b->stride = kmax;
+  b->cap2 = kmax;
+  {
+    uint32_t mb = 0;
+    b->unit_bound.resize((size_t)b->n_units);
+    for (int u = 0; u < b->n_units; u++) {
+      b->unit_bound[(size_t)u] = (uint32_t)std::min<uint64_t>(unit_bound[(size_t)u], 0x7fffffffu);
+      mb = std::max(mb, b->unit_bound[(size_t)u]);
+    }
+  }
+  // ---- fast-path geometry -----------------------------------------------------------------
+  // postings per unit held in registers: the smallest geometry that covers the largest expected
+  // unit with 25 % headroom; bigger units overflow to the general path one by one.
+  {
+    double est_max = 0.0;
+    for (double e : unit_est) est_max = std::max(est_max, e);
+    const double need = est_max * 1.25 + 32.0;
+    int ucap = 256;
+    while (ucap < 2048 && (double)ucap < need) ucap <<= 1;
+    b->fast.unit_capacity = ucap;
+    b->fast.k_local = 0;
+    // per-unit emission capacity: 3 x the k_local of the largest k, 32-aligned, at most 1024
+    double share = (double)kmax / ix->P;
+    int kl = (int)std::min<double>(kmax, share + 6.0 * std::sqrt(share) + 8.0);
+    int cap = ((3 * kl + 32 + 31) / 32) * 32;
+    b->cap = std::max(64, std::min(cap, 1024));
+    const char *force = getenv("SANN_FORCE_GENERAL");
+    b->use_fast = !(force && force[0] == '1');
+  }
 
   HIP_TRY(hipSetDevice(ix->device));
   size_t nu = (size_t)std::max(b->n_units, 1), nqz = (size_t)std::max(nq, 1);
   HIP_TRY(b->hdr.alloc(nqz * sizeof(QueryHdr)));
   HIP_TRY(b->scan_row.alloc(std::max<size_t>(b->h_scan_row.size(), 1) * 4));
   HIP_TRY(b->scan_w.alloc(std::max<size_t>(b->h_scan_w.size(), 1) * 8));
+  HIP_TRY(b->scan_q.alloc(std::max<size_t>(b->h_scan_q.size(), 1) * 4));
+  HIP_TRY(b->desc.alloc(std::max<size_t>(b->h_scan_row.size(), 1) * (size_t)ix->P * 8));
   HIP_TRY(b->d_k.alloc(nqz * 4));
   HIP_TRY(b->cand_key.alloc(nu * (size_t)b->cap * 8));
   HIP_TRY(b->cand_id.alloc(nu * (size_t)b->cap * 8));
   HIP_TRY(b->cand_cnt.alloc(nu * 4));
   HIP_TRY(b->unit_unique.alloc(nu * 4));
   HIP_TRY(b->unit_flags.alloc(nu * 4));
+  HIP_TRY(b->unit_fb.alloc(nu * 4));
+  HIP_TRY(b->unit_thr.alloc(nu * 16));
   HIP_TRY(b->status.alloc((nqz + 2) * 4));
   HIP_TRY(b->overflow_units.alloc(nu * 4));
   HIP_TRY(b->out_ids.alloc(nqz * (size_t)b->stride * 8));
@@ -444,59 +501,98 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
   if (!b->h_scan_row.empty()) {
     HIP_TRY(hipMemcpy(b->scan_row.p, b->h_scan_row.data(), b->h_scan_row.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->scan_w.p, b->h_scan_w.data(), b->h_scan_w.size() * 8, hipMemcpyHostToDevice));
-  }
-
-  // general-path workspace for every unit (the fast path, when enabled, only needs it for the
-  // units it flags; those regions are sized from the same bounds)
-  const char *force = getenv("SANN_FORCE_GENERAL");
-  b->use_fast = false;
-  (void)force;
-  {
-    std::vector<int64_t> off((size_t)b->n_units);
-    std::vector<uint32_t> slots((size_t)b->n_units);
-    int64_t run = 0;
-    for (int u = 0; u < b->n_units; u++) {
-      uint32_t S = next_pow2_u32(2 * unit_bound[(size_t)u] + 1);
-      off[(size_t)u] = run;
-      slots[(size_t)u] = S;
-      run += (int64_t)S + 1;
-    }
-    b->g_n = b->n_units;
-    b->g_entries = run;
-    HIP_TRY(b->g_off.alloc(nu * 8));
-    HIP_TRY(b->g_slots.alloc(nu * 4));
-    HIP_TRY(b->g_keys.alloc((size_t)std::max<int64_t>(run, 1) * 8));
-    HIP_TRY(b->g_dot.alloc((size_t)std::max<int64_t>(run, 1) * 8));
-    HIP_TRY(b->g_nsq.alloc((size_t)std::max<int64_t>(run, 1) * 8));
-    if (b->n_units > 0) {
-      HIP_TRY(hipMemcpy(b->g_off.p, off.data(), (size_t)b->n_units * 8, hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(b->g_slots.p, slots.data(), (size_t)b->n_units * 4, hipMemcpyHostToDevice));
-    }
+    HIP_TRY(hipMemcpy(b->scan_q.p, b->h_scan_q.data(), b->h_scan_q.size() * 4, hipMemcpyHostToDevice));
   }
   guard.b = nullptr;
   *out = b;
   return SANN_OK;
 }
 
-int sann_batch_run(sann_batch_t *b, void *hip_stream) {
-  if (!b) return fail(SANN_EINVAL, "batch is NULL");
-  hipStream_t st = (hipStream_t)hip_stream;
-  HIP_TRY(hipSetDevice(b->ix->device));
-  if (b->nq == 0) { b->ran = true; return SANN_OK; }
-  IndexView ixv = b->ix->view();
-  BatchView bv = b->view();
-  HIP_TRY(hipMemsetAsync(b->status.p, 0, ((size_t)b->nq + 2) * 4, st));
-  // general path over every unit
-  HIP_TRY(hipMemsetAsync(b->g_keys.p, 0xFF, (size_t)b->g_entries * 8, st));
+}  // extern "C"
+
+namespace {
+
+// Run the general (global-memory table) kernel on `units` (empty = every unit of the batch) and
+// leave their candidate lists in the cand_*2 buffers.  Buffers grow on demand.
+int run_general(sann_batch *b, const std::vector<int32_t> &units, hipStream_t st) {
+  const bool all = units.empty();
+  const int n = all ? b->n_units : (int)units.size();
+  if (n == 0) return SANN_OK;
+  std::vector<int64_t> off((size_t)n);
+  std::vector<uint32_t> slots((size_t)n);
+  int64_t run = 0;
+  for (int i = 0; i < n; i++) {
+    const int u = all ? i : units[(size_t)i];
+    uint32_t S = next_pow2_u32(2ull * b->unit_bound[(size_t)u] + 1);
+    off[(size_t)i] = run;
+    slots[(size_t)i] = S;
+    run += (int64_t)S + 1;
+  }
+  if (n > b->g_cap_units) {
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(b->g_units.alloc((size_t)n * 4));
+    HIP_TRY(b->g_off.alloc((size_t)n * 8));
+    HIP_TRY(b->g_slots.alloc((size_t)n * 4));
+    HIP_TRY(b->cand_key2.alloc((size_t)n * (size_t)b->cap2 * 8));
+    HIP_TRY(b->cand_id2.alloc((size_t)n * (size_t)b->cap2 * 8));
+    b->g_cap_units = n;
+  }
+  if (run > b->g_cap_entries) {
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(b->g_keys.alloc((size_t)run * 8));
+    HIP_TRY(b->g_dot.alloc((size_t)run * 8));
+    HIP_TRY(b->g_nsq.alloc((size_t)run * 8));
+    b->g_cap_entries = run;
+  }
+  // the tiny descriptor arrays are copied synchronously (pageable host memory)
+  if (!all) HIP_TRY(hipMemcpy(b->g_units.p, units.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->g_off.p, off.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->g_slots.p, slots.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemsetAsync(b->g_keys.p, 0xFF, (size_t)run * 8, st));
   GeneralWs ws;
-  ws.units = nullptr;
+  ws.units = all ? nullptr : b->g_units.as<int32_t>();
   ws.ws_off = b->g_off.as<int64_t>();
   ws.ws_slots = b->g_slots.as<uint32_t>();
   ws.keys = b->g_keys.as<int64_t>();
   ws.dot = b->g_dot.as<double>();
   ws.nsq = b->g_nsq.as<double>();
-  HIP_TRY(launch_unit_general(ixv, bv, ws, b->n_units, st));
-  HIP_TRY(launch_merge(ixv, bv, nullptr, b->nq, st));
+  HIP_TRY(launch_unit_general(b->ix->view(), b->view(), ws, n, st));
+  return SANN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sann_batch_run(sann_batch_t *b, void *hip_stream) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(hipSetDevice(b->ix->device));
+  if (b->nq == 0) { b->ran = true; return SANN_OK; }
+  HIP_TRY(hipMemsetAsync(b->status.p, 0, ((size_t)b->nq + 2) * 4, st));
+  HIP_TRY(hipMemsetAsync(b->unit_fb.p, 0xFF, (size_t)b->n_units * 4, st));
+  if (!b->use_fast && b->g_cap_units < b->n_units) {
+    // all-general mode: size the workspace before the timed launches
+    std::vector<int32_t> none;
+    if (b->profiling) HIP_TRY(hipEventRecord(b->ev[0], st));
+    int rc = run_general(b, none, st);
+    if (rc != SANN_OK) return rc;
+  } else {
+    if (b->profiling) HIP_TRY(hipEventRecord(b->ev[0], st));
+    if (b->use_fast) {
+      hipError_t e = launch_desc(b->ix->view(), b->view(), (int)b->h_scan_row.size(), st);
+      if (e != hipSuccess) return fail(SANN_EDEVICE, std::string("launch_desc: ") + hipGetErrorString(e));
+      e = launch_unit_fast(b->ix->view(), b->view(), b->fast, b->n_units, st);
+      if (e != hipSuccess) return fail(SANN_EDEVICE, std::string("launch_unit_fast: ") + hipGetErrorString(e));
+    } else {
+      std::vector<int32_t> none;
+      int rc = run_general(b, none, st);
+      if (rc != SANN_OK) return rc;
+    }
+  }
+  if (b->profiling) HIP_TRY(hipEventRecord(b->ev[1], st));
+  HIP_TRY(launch_merge(b->ix->view(), b->view(), nullptr, b->nq, st));
+  if (b->profiling) { HIP_TRY(hipEventRecord(b->ev[2], st)); b->ev_pending = true; }
   HIP_TRY(hipMemcpyAsync(b->h_status, b->status.p, 2 * 4, hipMemcpyDeviceToHost, st));
   b->ran = true;
   return SANN_OK;
@@ -509,8 +605,52 @@ int sann_batch_finish(sann_batch_t *b, void *hip_stream) {
   HIP_TRY(hipSetDevice(b->ix->device));
   HIP_TRY(hipStreamSynchronize(st));
   if (b->nq == 0) return SANN_OK;
+  if (b->ev_pending) {
+    float a = 0.f, c = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, b->ev[0], b->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&c, b->ev[1], b->ev[2]));
+    b->unit_ms_total += a;
+    b->merge_ms_total += c;
+    b->timed_runs++;
+    b->ev_pending = false;
+  }
+  const int n_over = b->h_status[0], n_inexact = b->h_status[1];
+  if (n_over == 0 && n_inexact == 0) return SANN_OK;
+  if (!b->use_fast) return fail(SANN_EINTERNAL, "general path reported overflow/inexact units");
+
+  // ---- slow tail: re-run on the general path whatever the fast path could not settle ---------
+  const int P = b->ix->P;
+  std::vector<int32_t> over((size_t)n_over), inexact((size_t)n_inexact);
+  if (n_over) HIP_TRY(hipMemcpy(over.data(), b->overflow_units.p, (size_t)n_over * 4, hipMemcpyDeviceToHost));
+  if (n_inexact)
+    HIP_TRY(hipMemcpy(inexact.data(), b->status.as<int32_t>() + 2, (size_t)n_inexact * 4, hipMemcpyDeviceToHost));
+  std::vector<uint8_t> q_mark((size_t)b->nq, 0), q_full((size_t)b->nq, 0);
+  for (int32_t q : inexact) { q_mark[(size_t)q] = 1; q_full[(size_t)q] = 1; }
+  std::vector<int32_t> units, queries;
+  for (int32_t u : over) {
+    int q = u / P;
+    q_mark[(size_t)q] = 1;
+    if (!q_full[(size_t)q]) units.push_back(u);
+  }
+  for (int q = 0; q < b->nq; q++) {
+    if (q_full[(size_t)q])
+      for (int p = 0; p < P; p++) units.push_back(q * P + p);
+    if (q_mark[(size_t)q]) queries.push_back(q);
+  }
+  std::sort(units.begin(), units.end());
+  units.erase(std::unique(units.begin(), units.end()), units.end());
+  int rc = run_general(b, units, st);
+  if (rc != SANN_OK) return rc;
+  HIP_TRY(b->g_queries.alloc(queries.size() * 4));
+  HIP_TRY(hipMemcpy(b->g_queries.p, queries.data(), queries.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemsetAsync(b->status.p, 0, 2 * 4, st));
+  HIP_TRY(launch_merge(b->ix->view(), b->view(), b->g_queries.as<int32_t>(), (int)queries.size(), st));
+  HIP_TRY(hipMemcpyAsync(b->h_status, b->status.p, 2 * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  b->stats.n_fallback_units += (int32_t)units.size();
+  b->stats.n_requeried += n_inexact;
   if (b->h_status[0] != 0 || b->h_status[1] != 0)
-    return fail(SANN_EINTERNAL, "general path reported overflow/inexact units");
+    return fail(SANN_EINTERNAL, "general path could not settle the flagged units");
   return SANN_OK;
 }
 
@@ -520,25 +660,38 @@ int sann_batch_results(sann_batch_t *b, int64_t *out_ids, double *out_scores, in
   if (b->nq == 0) return SANN_OK;
   if (out_stride < b->stride) return fail(SANN_EINVAL, "out_stride smaller than the batch's max k");
   HIP_TRY(hipSetDevice(b->ix->device));
+  BatchView bv = b->view();
   if (out_ids)
-    HIP_TRY(hipMemcpy2D(out_ids, (size_t)out_stride * 8, b->out_ids.p, (size_t)b->stride * 8, (size_t)b->stride * 8,
+    HIP_TRY(hipMemcpy2D(out_ids, (size_t)out_stride * 8, bv.out_ids, (size_t)b->stride * 8, (size_t)b->stride * 8,
                         (size_t)b->nq, hipMemcpyDeviceToHost));
   if (out_scores)
-    HIP_TRY(hipMemcpy2D(out_scores, (size_t)out_stride * 8, b->out_scores.p, (size_t)b->stride * 8,
+    HIP_TRY(hipMemcpy2D(out_scores, (size_t)out_stride * 8, bv.out_scores, (size_t)b->stride * 8,
                         (size_t)b->stride * 8, (size_t)b->nq, hipMemcpyDeviceToHost));
-  if (out_counts) HIP_TRY(hipMemcpy(out_counts, b->out_counts.p, (size_t)b->nq * 4, hipMemcpyDeviceToHost));
-  if (out_map_sizes) HIP_TRY(hipMemcpy(out_map_sizes, b->out_map_sizes.p, (size_t)b->nq * 4, hipMemcpyDeviceToHost));
+  if (out_counts) HIP_TRY(hipMemcpy(out_counts, bv.out_counts, (size_t)b->nq * 4, hipMemcpyDeviceToHost));
+  if (out_map_sizes) HIP_TRY(hipMemcpy(out_map_sizes, bv.out_map_sizes, (size_t)b->nq * 4, hipMemcpyDeviceToHost));
   return SANN_OK;
 }
 
 int sann_batch_device_results(sann_batch_t *b, void **d_ids, void **d_scores, void **d_counts, void **d_map_sizes,
                               int32_t *stride) {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
-  if (d_ids) *d_ids = b->out_ids.p;
-  if (d_scores) *d_scores = b->out_scores.p;
-  if (d_counts) *d_counts = b->out_counts.p;
-  if (d_map_sizes) *d_map_sizes = b->out_map_sizes.p;
+  BatchView bv = b->view();
+  if (d_ids) *d_ids = bv.out_ids;
+  if (d_scores) *d_scores = bv.out_scores;
+  if (d_counts) *d_counts = bv.out_counts;
+  if (d_map_sizes) *d_map_sizes = bv.out_map_sizes;
   if (stride) *stride = b->stride;
+  return SANN_OK;
+}
+
+int sann_batch_bind_outputs(sann_batch_t *b, void *d_ids, void *d_scores, void *d_counts, void *d_map_sizes) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  bool all = d_ids && d_scores && d_counts && d_map_sizes, none = !d_ids && !d_scores && !d_counts && !d_map_sizes;
+  if (!all && !none) return fail(SANN_EINVAL, "bind all four output buffers or none");
+  b->bound_ids = d_ids;
+  b->bound_scores = d_scores;
+  b->bound_counts = d_counts;
+  b->bound_map_sizes = d_map_sizes;
   return SANN_OK;
 }
 
@@ -551,6 +704,33 @@ int sann_batch_device_k(sann_batch_t *b, void **d_k) {
 int sann_batch_stats(sann_batch_t *b, sann_batch_stats_t *stats) {
   if (!b || !stats) return fail(SANN_EINVAL, "NULL argument");
   *stats = b->stats;
+  return SANN_OK;
+}
+
+int sann_batch_set_profiling(sann_batch_t *b, int32_t enable) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  if (enable)
+    for (auto &e : b->ev)
+      if (!e) HIP_TRY(hipEventCreate(&e));
+  b->profiling = enable != 0;
+  b->unit_ms_total = b->merge_ms_total = 0.0;
+  b->timed_runs = 0;
+  b->ev_pending = false;
+  return SANN_OK;
+}
+
+int sann_batch_kernel_times(sann_batch_t *b, double *unit_ms_total, double *merge_ms_total, int32_t *n_runs) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  if (unit_ms_total) *unit_ms_total = b->unit_ms_total;
+  if (merge_ms_total) *merge_ms_total = b->merge_ms_total;
+  if (n_runs) *n_runs = b->timed_runs;
+  return SANN_OK;
+}
+
+int sann_device_synchronize(int32_t device) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipDeviceSynchronize());
   return SANN_OK;
 }
 
@@ -580,8 +760,9 @@ int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_
   return rc;
 }
 
-int sann_merge_shards(int32_t device, void *hip_stream, int32_t n_shards, int32_t nq, int32_t stride, const void *d_ids,
-                      const void *d_scores, const void *d_counts, const void *d_map_sizes, const void *d_k,
+int sann_merge_shards(int32_t device, void *hip_stream, int32_t n_shards, int32_t nq, int32_t stride,
+                      int64_t shard_pitch_bytes, const void *d_ids, const void *d_scores, const void *d_counts,
+                      const void *d_map_sizes, const void *d_k,
                       void *d_out_ids, void *d_out_scores, void *d_out_counts, void *d_out_map_sizes) {
   if (n_shards < 1 || nq < 0 || stride < 1 || stride > 1024) return fail(SANN_EINVAL, "bad merge sizes");
   if (nq == 0) return SANN_OK;
@@ -589,7 +770,8 @@ int sann_merge_shards(int32_t device, void *hip_stream, int32_t n_shards, int32_
       !d_out_map_sizes)
     return fail(SANN_EINVAL, "NULL device pointer");
   HIP_TRY(hipSetDevice(device));
-  HIP_TRY(launch_merge_shards(n_shards, nq, stride, (const int64_t *)d_ids, (const double *)d_scores,
+  if (shard_pitch_bytes < 0 || (shard_pitch_bytes & 7)) return fail(SANN_EINVAL, "shard_pitch_bytes must be a non-negative multiple of 8");
+  HIP_TRY(launch_merge_shards(n_shards, nq, stride, shard_pitch_bytes, (const int64_t *)d_ids, (const double *)d_scores,
                               (const int32_t *)d_counts, (const int32_t *)d_map_sizes, (const int32_t *)d_k,
                               (int64_t *)d_out_ids, (double *)d_out_scores, (int32_t *)d_out_counts,
                               (int32_t *)d_out_map_sizes, (hipStream_t)hip_stream));

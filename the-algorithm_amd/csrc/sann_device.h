@@ -51,22 +51,31 @@ struct IndexView {
 enum : uint32_t {
   UNIT_OK = 0,
   UNIT_OVERFLOW = 1,   // fast path could not hold the unit (table, dup list or scan list too big)
-  UNIT_TRUNCATED = 2,  // unit had more qualifying candidates than it emitted
+  UNIT_TRUNCATED = 2,  // unit withheld qualifying candidates: all of them have key < unit_thr
 };
 
 struct BatchView {
   const QueryHdr *hdr;
   const int32_t *scan_row;
   const double *scan_w;
+  const int32_t *scan_q;    // [total_scan] query of every scan entry
+  uint32_t *desc;           // [total_scan*P*2] (sub-list start, #postings with rank < M), unit-major
   int32_t nq;
-  int32_t cap;              // entries per unit in cand_* (>= max k of the batch)
-  // per unit outputs
-  uint64_t *cand_key;       // [n_units*cap] monotone score key
-  int64_t *cand_id;         // [n_units*cap]
+  int32_t cap;              // entries per unit in cand_key/cand_id (fast path)
+  int32_t cap2;             // entries per unit in cand_key2/cand_id2 (general path, >= max k)
+  // per unit candidate lists.  Unit u's list is at cand_*[u*cap] when unit_fb[u] < 0, else at
+  // cand_*2[unit_fb[u]*cap2].
+  uint64_t *cand_key;       // monotone score key
+  int64_t *cand_id;
+  uint64_t *cand_key2;
+  int64_t *cand_id2;
+  int32_t *unit_fb;         // [n_units]
   int32_t *cand_cnt;        // [n_units]
   int32_t *unit_unique;     // [n_units] distinct tweets accumulated (candidateScoresMap.size share)
   uint32_t *unit_flags;     // [n_units]
-  // batch status: [0] = number of overflowed units, [1] = number of inexact queries
+  uint64_t *unit_thr;       // [n_units*2] (hi, lo): every withheld candidate has key < thr
+  // batch status: [0] = number of overflowed units, [1] = number of inexact queries,
+  // [2..2+nq) = list of inexact queries
   int32_t *status;
   int32_t *overflow_units;  // [n_units] list of overflowed unit ids (first status[0] entries)
   // final per-query outputs
@@ -97,10 +106,16 @@ __host__ __device__ inline uint64_t mix64(uint64_t x) {
   x ^= x >> 33;
   return x;
 }
-// tweet -> (shard, partition).  Shard from the high bits, partition from the low bits, table
-// slot from the middle bits, so the three are independent.
+// tweet -> (shard, partition).  Shard from the high bits, partition from the low bits.
 __host__ __device__ inline uint32_t tweet_shard(uint64_t h, uint32_t n_shards) { return (uint32_t)((h >> 40) % n_shards); }
 __host__ __device__ inline uint32_t tweet_partition(uint64_t h, uint32_t P) { return (uint32_t)(h & (P - 1)); }
 __host__ __device__ inline uint32_t tweet_slot(uint64_t h) { return (uint32_t)(h >> 12); }
+// Cheap in-table hash (the partition hash above is fixed at index build; this one only places a
+// key inside one unit's table): fold to 32 bits, Fibonacci multiply, take the top bits.
+__host__ __device__ inline uint32_t table_hash(int64_t id, int log2S) {
+  uint32_t x = (uint32_t)((uint64_t)id ^ ((uint64_t)id >> 32));
+  x ^= x >> 15;
+  return (x * 0x9E3779B1u) >> (32 - log2S);
+}
 
 }  // namespace sann

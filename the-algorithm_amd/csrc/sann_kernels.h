@@ -10,7 +10,7 @@ hipError_t launch_unit_general(const IndexView &ix, const BatchView &b, const Ge
                                hipStream_t stream);
 hipError_t launch_merge(const IndexView &ix, const BatchView &b, const int32_t *query_list, int n_queries,
                         hipStream_t stream);
-hipError_t launch_merge_shards(int n_shards, int nq, int stride, const int64_t *ids, const double *scores,
+hipError_t launch_merge_shards(int n_shards, int nq, int stride, int64_t shard_pitch_bytes, const int64_t *ids, const double *scores,
                                const int32_t *counts, const int32_t *map_sizes, const int32_t *k, int64_t *out_ids,
                                double *out_scores, int32_t *out_counts, int32_t *out_map_sizes, hipStream_t stream);
 
@@ -20,9 +20,10 @@ hipError_t launch_debug_normalise(int alg, int n, const double *dot, const doubl
 // LDS fast path (sann_fast.hip).  Returns hipErrorInvalidValue when the configuration cannot
 // run on the fast path at all (the caller then uses the general path for every unit).
 struct FastParams {
-  int table_slots;  // LDS hash slots per unit (power of two)
-  int k_local;      // entries a unit must emit before it may truncate
+  int unit_capacity;  // postings one unit holds in registers (workgroup size x postings per thread)
+  int k_local;        // floor on the entries a unit must offer before it may withhold the rest
 };
+hipError_t launch_desc(const IndexView &ix, const BatchView &b, int total_scan, hipStream_t stream);
 hipError_t launch_unit_fast(const IndexView &ix, const BatchView &b, const FastParams &fp, int n_units,
                             hipStream_t stream);
 

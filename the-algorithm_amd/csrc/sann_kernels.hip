@@ -1,4 +1,4 @@
-// sann_kernels.hip -- gfx950 kernels of the SimClusters-ANN hot path.
+// sann_kernels.hip -- gfx950 kernels of the SimClusters-ANN hot path (general path + merges).
 //
 // Reference semantics (paths relative to /root/reference/):
 //   simclusters-ann/server/src/main/scala/com/twitter/simclustersann/candidate_source/
@@ -10,8 +10,11 @@
 //                        Always correct for any size / duplication; it is the fallback of the
 //                        LDS fast path (sann_fast.hip) and the first path that was parity-green.
 //   merge_kernel         one workgroup per query: exact top-k over the units' candidates under
-//                        the total order (score desc by Double.compare, tweet id asc), bitonic
-//                        sort of the k winners in LDS, final outputs.
+//                        the total order (score desc by Double.compare, tweet id asc).  Small
+//                        inputs (<= 4096 entries, the normal case) are bitonic-sorted in LDS;
+//                        larger ones go through an MSB radix select first.  Also proves the
+//                        result exact: a unit that withheld candidates below its threshold is
+//                        harmless iff that threshold is <= the global k-th key.
 //   merge_shards_kernel  the same merge over all-gathered per-shard results.
 //
 // Compiled with -ffp-contract=off (see sann_math.h).
@@ -20,11 +23,13 @@
 #include "sann_device.h"
 #include "sann_kernels.h"
 #include "sann_math.h"
+#include "sann_select.h"
 
 namespace sann {
 
 constexpr int WG = 256;
-constexpr int KMAX = 1024;  // >= MaxNumResultsUpperBound (1000), ApproximateCosineSimilarity.scala:41
+constexpr int KMAX = 1024;       // >= MaxNumResultsUpperBound (1000), ApproximateCosineSimilarity.scala:41
+constexpr int MERGE_LDS = 4096;  // entries the merge can sort in LDS
 
 // ---------------------------------------------------------------------------------------------
 // normalisation, ApproximateCosineSimilarity.scala:111-119
@@ -57,6 +62,9 @@ __device__ inline unsigned digit_of(uint64_t hi, uint64_t lo, int pass) {
 }
 __device__ inline bool key_ge(uint64_t hi, uint64_t lo, uint64_t thi, uint64_t tlo) {
   return hi > thi || (hi == thi && lo >= tlo);
+}
+__device__ inline bool key_gt(uint64_t hi, uint64_t lo, uint64_t thi, uint64_t tlo) {
+  return hi > thi || (hi == thi && lo > tlo);
 }
 
 // Src: int size(); bool get(int i, uint64_t& hi, uint64_t& lo)  (false = slot not a candidate)
@@ -94,23 +102,11 @@ __device__ void wg_select_threshold(const Src &src, int k, unsigned *s_hist, int
       if (src.get(i, hi, lo) && prefix_match(hi, lo, phi, plo, pass)) atomicAdd(&s_hist[digit_of(hi, lo, pass)], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      int cum = 0;
-      for (int d = 255; d >= 0; d--) {
-        int c = (int)s_hist[d];
-        if (cum + c >= need) {
-          s_ctl[1] = d;
-          s_ctl[2] = need - cum;
-          s_ctl[3] = (c == need - cum);
-          break;
-        }
-        cum += c;
-      }
-    }
+    if (tid < 64) wave_find_digit(s_hist, need, &s_ctl[1]);  // d, entries above d, entries in d
     __syncthreads();
     uint64_t d = (uint64_t)s_ctl[1];
-    need = s_ctl[2];
-    int done = s_ctl[3];
+    const int done = (s_ctl[3] == need - s_ctl[2]);
+    need = need - s_ctl[2];
     if (pass < 8) phi |= d << (56 - 8 * pass);
     else plo |= d << (56 - 8 * (pass - 8));
     __syncthreads();
@@ -131,8 +127,8 @@ __device__ void bitonic_sort_desc(uint64_t *hi, uint64_t *lo, int n) {
         bool desc = ((i & size) == 0);
         uint64_t ah = hi[i], al = lo[i], bh = hi[j], bl = lo[j];
         bool a_lt_b = ah < bh || (ah == bh && al < bl);
-        bool swap = desc ? a_lt_b : !a_lt_b && !(ah == bh && al == bl);
-        if (swap) {
+        bool a_gt_b = ah > bh || (ah == bh && al > bl);
+        if (desc ? a_lt_b : a_gt_b) {
           hi[i] = bh; lo[i] = bl;
           hi[j] = ah; lo[j] = al;
         }
@@ -252,63 +248,79 @@ __global__ __launch_bounds__(WG) void unit_general_kernel(IndexView ix, BatchVie
   TableSrc src{keys, dot, nsq, (int)S + 1};
   uint64_t thi, tlo;
   int n_valid;
-  const int kk = h.k < b.cap ? h.k : b.cap;
+  const int kk = h.k < b.cap2 ? h.k : b.cap2;
   wg_select_threshold(src, kk, s_hist, s_ctl, thi, tlo, n_valid);
-  const int64_t obase = (int64_t)unit * b.cap;
+  const int64_t obase = (int64_t)blk * b.cap2;
   for (int i = tid; i <= (int)S; i += WG) {
     uint64_t hi, lo;
     if (src.get(i, hi, lo) && key_ge(hi, lo, thi, tlo)) {
       int o = atomicAdd(&s_cnt, 1);
-      if (o < b.cap) {
-        b.cand_key[obase + o] = hi;
-        b.cand_id[obase + o] = (i == (int)S) ? kEmptyKey : keys[i];
+      if (o < b.cap2) {
+        b.cand_key2[obase + o] = hi;
+        b.cand_id2[obase + o] = (i == (int)S) ? kEmptyKey : keys[i];
       }
     }
   }
   __syncthreads();
   if (tid == 0) {
-    b.cand_cnt[unit] = s_cnt < b.cap ? s_cnt : b.cap;
+    b.unit_fb[unit] = blk;
+    b.cand_cnt[unit] = s_cnt < b.cap2 ? s_cnt : b.cap2;
     b.unit_unique[unit] = s_unique;
-    b.unit_flags[unit] = (n_valid > s_cnt) ? UNIT_TRUNCATED : UNIT_OK;
+    const bool trunc = n_valid > s_cnt;
+    b.unit_flags[unit] = trunc ? UNIT_TRUNCATED : UNIT_OK;
+    b.unit_thr[2 * (int64_t)unit] = trunc ? thi : 0;
+    b.unit_thr[2 * (int64_t)unit + 1] = trunc ? tlo : 0;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Merge: exact top-k over P unit lists of one query.
 // ---------------------------------------------------------------------------------------------
+__device__ inline void unit_list(const BatchView &b, int64_t unit, const uint64_t *&key, const int64_t *&id) {
+  const int fb = b.unit_fb[unit];
+  if (fb < 0) {
+    key = b.cand_key + unit * b.cap;
+    id = b.cand_id + unit * b.cap;
+  } else {
+    key = b.cand_key2 + (int64_t)fb * b.cap2;
+    id = b.cand_id2 + (int64_t)fb * b.cap2;
+  }
+}
+
 struct UnitListSrc {
-  const uint64_t *cand_key;
-  const int64_t *cand_id;
-  const int32_t *cand_cnt;
+  const BatchView *b;
   int64_t unit0;  // first unit of the query
-  int P, cap;
-  __device__ int size() const { return P * cap; }
+  int P, capmax;
+  __device__ int size() const { return P * capmax; }
   __device__ bool get(int i, uint64_t &hi, uint64_t &lo) const {
-    int u = i / cap, j = i - u * cap;
-    if (j >= cand_cnt[unit0 + u]) return false;
-    hi = cand_key[(unit0 + u) * cap + j];
-    lo = id_key(cand_id[(unit0 + u) * cap + j]);
+    int u = i / capmax, j = i - u * capmax;
+    if (j >= b->cand_cnt[unit0 + u]) return false;
+    const uint64_t *key;
+    const int64_t *id;
+    unit_list(*b, unit0 + u, key, id);
+    hi = key[j];
+    lo = id_key(id[j]);
     return true;
   }
 };
 
+// Select (radix) + sort (LDS bitonic) + write.  Returns the k-th key through xk (0,0 = none).
 template <class Src>
 __device__ void merge_select_sort_write(const Src &src, int k, int64_t *out_ids, double *out_scores, int32_t *out_count,
                                         uint64_t *s_hi, uint64_t *s_lo, unsigned *s_hist, int *s_ctl, int *s_cnt,
-                                        int *s_sel_per_list /* may be NULL */, int cap_per_list) {
+                                        uint64_t &xk_hi, uint64_t &xk_lo) {
   const int tid = threadIdx.x;
-  uint64_t thi, tlo;
   int n_valid;
-  wg_select_threshold(src, k, s_hist, s_ctl, thi, tlo, n_valid);
+  wg_select_threshold(src, k, s_hist, s_ctl, xk_hi, xk_lo, n_valid);
+  if (n_valid < k) { xk_hi = 0; xk_lo = 0; }
   if (tid == 0) *s_cnt = 0;
   __syncthreads();
   const int n = src.size();
   for (int i = tid; i < n; i += WG) {
     uint64_t hi, lo;
-    if (src.get(i, hi, lo) && key_ge(hi, lo, thi, tlo)) {
+    if (k > 0 && src.get(i, hi, lo) && key_ge(hi, lo, xk_hi, xk_lo)) {
       int o = atomicAdd(s_cnt, 1);
       if (o < KMAX) { s_hi[o] = hi; s_lo[o] = lo; }
-      if (s_sel_per_list) atomicAdd(&s_sel_per_list[i / cap_per_list], 1);
     }
   }
   __syncthreads();
@@ -325,34 +337,160 @@ __device__ void merge_select_sort_write(const Src &src, int k, int64_t *out_ids,
 }
 
 __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, const int32_t *query_list) {
-  __shared__ uint64_t s_hi[KMAX], s_lo[KMAX];
+  __shared__ uint64_t s_hi[MERGE_LDS], s_lo[MERGE_LDS];
+  __shared__ uint64_t s_hi2[KMAX], s_lo2[KMAX];
+  __shared__ uint64_t s_mm[2];
   __shared__ unsigned s_hist[256];
+  __shared__ int s_off[WG + 1];
   __shared__ int s_ctl[4];
   __shared__ int s_cnt;
-  __shared__ int s_sel[256];  // P <= 256
 
   const int tid = threadIdx.x;
   const int q = query_list ? query_list[blockIdx.x] : blockIdx.x;
   const QueryHdr h = b.hdr[q];
-  for (int i = tid; i < 256; i += WG) s_sel[i] = 0;
-  __syncthreads();
-  UnitListSrc src{b.cand_key, b.cand_id, b.cand_cnt, (int64_t)q * ix.P, ix.P, b.cap};
-  merge_select_sort_write(src, h.k, b.out_ids + (int64_t)q * b.stride, b.out_scores + (int64_t)q * b.stride,
-                          b.out_counts + q, s_hi, s_lo, s_hist, s_ctl, &s_cnt, s_sel, b.cap);
-  __syncthreads();
-  // candidateScoresMap.size (:102) and the exactness check for truncated units
-  int msz = 0, inexact = 0;
-  const int cnt = s_cnt < KMAX ? s_cnt : KMAX;
-  for (int u = tid; u < ix.P; u += WG) {
-    int64_t unit = (int64_t)q * ix.P + u;
-    msz += b.unit_unique[unit];
-    uint32_t f = b.unit_flags[unit];
-    int emitted = b.cand_cnt[unit];
-    // a unit that withheld candidates is only harmless if one of its emitted entries lost
-    // (then everything it withheld is worse than the global k-th), or it emitted a full k.
-    if ((f & UNIT_TRUNCATED) && emitted < h.k && (s_sel[u] == emitted || cnt < h.k)) inexact = 1;
+  const int P = ix.P;  // <= 256
+  const int64_t unit0 = (int64_t)q * P;
+
+  // offsets of the unit lists in a flat index space (P <= 256: one thread per unit, wave scans)
+  {
+    int c = tid < P ? b.cand_cnt[unit0 + tid] : 0;
+    int incl = c;
+    const int lane = tid & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_ctl[tid >> 6] = incl;  // wave totals (WG/64 = 4 waves)
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < (tid >> 6); w++) wbase += s_ctl[w];
+    s_off[tid] = wbase + incl - c;
+    if (tid == WG - 1) s_off[WG] = wbase + incl;
+    __syncthreads();
   }
-  if (tid == 0) s_ctl[0] = 0, s_ctl[1] = 0;
+  const int total = s_off[WG];
+  uint64_t xk_hi = 0, xk_lo = 0;
+  int64_t *out_ids = b.out_ids + (int64_t)q * b.stride;
+  double *out_scores = b.out_scores + (int64_t)q * b.stride;
+
+  if (total <= MERGE_LDS) {
+    // stage every entry in LDS
+    for (int i = tid; i < total; i += WG) {
+      int u = 0;
+#pragma unroll
+      for (int step = 128; step >= 1; step >>= 1) {
+        int t = u + step;
+        if (t < WG && s_off[t] <= i) u = t;
+      }
+      const uint64_t *key;
+      const int64_t *id;
+      unit_list(b, unit0 + u, key, id);
+      const int j = i - s_off[u];
+      s_hi[i] = key[j];
+      s_lo[i] = id_key(id[j]);
+    }
+    __syncthreads();
+    // cut to the entries that can matter: radix threshold on the score key so that between k
+    // and KMAX entries survive, then sort only those
+    uint64_t *srt_hi = s_hi, *srt_lo = s_lo;
+    int n_sort = total;
+    if (total > h.k + 128 && h.k > 0) {
+      // min / max of the keys
+      uint64_t kmin = ~0ull, kmax = 0ull;
+      for (int i = tid; i < total; i += WG) {
+        const uint64_t k = s_hi[i];
+        kmin = k < kmin ? k : kmin;
+        kmax = k > kmax ? k : kmax;
+      }
+      if (tid == 0) { s_mm[0] = ~0ull; s_mm[1] = 0ull; }
+      __syncthreads();
+      atomicMin((unsigned long long *)&s_mm[0], (unsigned long long)kmin);
+      atomicMax((unsigned long long *)&s_mm[1], (unsigned long long)kmax);
+      __syncthreads();
+      const uint64_t gmin = s_mm[0], gmax = s_mm[1];
+      const uint64_t diff = gmin ^ gmax;
+      uint64_t prefix = 0;
+      bool ok = diff != 0;
+      if (ok) {
+        const int hbit = 63 - __clzll((long long)diff);
+        int shift = hbit - 7 < 0 ? 0 : hbit - 7;
+        int width = hbit - shift + 1;
+        prefix = (hbit == 63) ? 0ull : (gmax >> (hbit + 1)) << (hbit + 1);
+        int need = h.k, budget = KMAX;
+        for (;;) {
+          for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
+          __syncthreads();
+          const uint64_t hi_mask = (shift + width >= 64) ? 0ull : (~0ull << (shift + width));
+          for (int i = tid; i < total; i += WG) {
+            const uint64_t k = s_hi[i];
+            if ((k & hi_mask) == (prefix & hi_mask)) atomicAdd(&s_hist[(unsigned)((k >> shift) & ((1u << width) - 1))], 1u);
+          }
+          __syncthreads();
+          if (tid < 64) wave_find_digit(s_hist, need, &s_ctl[1]);
+          __syncthreads();
+          const int d = s_ctl[1], A = s_ctl[2], B = s_ctl[3];
+          prefix |= (uint64_t)d << shift;
+          bool stop = false;
+          if (A + B <= budget) stop = true;
+          else if (shift == 0) { ok = false; stop = true; }  // too many exact ties: sort everything
+          else {
+            need -= A; budget -= A;
+            const int ns = shift - 8 < 0 ? 0 : shift - 8;
+            width = shift - ns; shift = ns;
+          }
+          __syncthreads();
+          if (stop) break;
+        }
+      }
+      if (ok) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        for (int i = tid; i < total; i += WG) {
+          const uint64_t k = s_hi[i];
+          if (k >= prefix) {
+            const int o = atomicAdd(&s_cnt, 1);
+            s_hi2[o] = k;
+            s_lo2[o] = s_lo[i];
+          }
+        }
+        __syncthreads();
+        n_sort = s_cnt;
+        srt_hi = s_hi2;
+        srt_lo = s_lo2;
+      }
+    }
+    const int np = next_pow2(n_sort);
+    for (int i = n_sort + tid; i < np; i += WG) { srt_hi[i] = 0; srt_lo[i] = 0; }
+    __syncthreads();
+    bitonic_sort_desc(srt_hi, srt_lo, np);
+    const int cnt = n_sort < h.k ? n_sort : h.k;
+    for (int i = tid; i < cnt; i += WG) {
+      out_ids[i] = key_id(srt_lo[i]);
+      out_scores[i] = key_score(srt_hi[i]);
+    }
+    if (cnt == h.k && cnt > 0) { xk_hi = srt_hi[cnt - 1]; xk_lo = srt_lo[cnt - 1]; }
+    if (tid == 0) b.out_counts[q] = cnt;
+  } else {
+    const int capmax = b.cap > b.cap2 ? b.cap : b.cap2;
+    UnitListSrc src{&b, unit0, P, capmax};
+    merge_select_sort_write(src, h.k, out_ids, out_scores, b.out_counts + q, s_hi, s_lo, s_hist, s_ctl, &s_cnt, xk_hi,
+                            xk_lo);
+  }
+  __syncthreads();
+  // candidateScoresMap.size (:102) and the exactness proof: every candidate a unit withheld has
+  // key < unit_thr; it cannot belong to the top-k iff unit_thr <= the k-th key.  With fewer than
+  // k results there is no k-th key, so any withholding unit makes the result unproven.
+  int msz = 0, inexact = 0;
+  for (int u = tid; u < P; u += WG) {
+    const int64_t unit = unit0 + u;
+    msz += b.unit_unique[unit];
+    if (h.k > 0 && (b.unit_flags[unit] & UNIT_TRUNCATED)) {
+      const uint64_t thi = b.unit_thr[2 * unit], tlo = b.unit_thr[2 * unit + 1];
+      if (key_gt(thi, tlo, xk_hi, xk_lo)) inexact = 1;
+    }
+  }
+  if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
   __syncthreads();
   if (msz) atomicAdd(&s_ctl[0], msz);
   if (inexact) atomicOr(&s_ctl[1], 1);
@@ -366,40 +504,47 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   }
 }
 
-// Per-shard results (already sorted rows) -> global top-k.
+// Per-shard results (already exact per shard) -> global top-k.  Shard s's arrays start pitch
+// bytes after shard s-1's (pitch 0 = each array tightly packed shard-major, i.e.
+// ids[n_shards][nq][stride], counts[n_shards][nq]).
 struct ShardSrc {
   const int64_t *ids;
   const double *scores;
   const int32_t *counts;
   int n_shards, nq, stride, q;
+  int64_t pitch_ids, pitch_cnt;  // bytes
   __device__ int size() const { return n_shards * stride; }
   __device__ bool get(int i, uint64_t &hi, uint64_t &lo) const {
     int s = i / stride, j = i - s * stride;
-    if (j >= counts[(int64_t)s * nq + q]) return false;
-    int64_t o = ((int64_t)s * nq + q) * stride + j;
-    hi = score_key(scores[o]);
-    lo = id_key(ids[o]);
+    const int32_t *c = (const int32_t *)((const char *)counts + s * pitch_cnt);
+    if (j >= c[q]) return false;
+    int64_t o = (int64_t)q * stride + j;
+    hi = score_key(((const double *)((const char *)scores + s * pitch_ids))[o]);
+    lo = id_key(((const int64_t *)((const char *)ids + s * pitch_ids))[o]);
     return true;
   }
 };
 
-__global__ __launch_bounds__(WG) void merge_shards_kernel(int n_shards, int nq, int stride, const int64_t *ids,
-                                                         const double *scores, const int32_t *counts,
-                                                         const int32_t *map_sizes, const int32_t *k, int64_t *out_ids,
-                                                         double *out_scores, int32_t *out_counts,
-                                                         int32_t *out_map_sizes) {
+__global__ __launch_bounds__(WG) void merge_shards_kernel(int n_shards, int nq, int stride, int64_t pitch,
+                                                         const int64_t *ids, const double *scores,
+                                                         const int32_t *counts, const int32_t *map_sizes,
+                                                         const int32_t *k, int64_t *out_ids, double *out_scores,
+                                                         int32_t *out_counts, int32_t *out_map_sizes) {
   __shared__ uint64_t s_hi[KMAX], s_lo[KMAX];
   __shared__ unsigned s_hist[256];
   __shared__ int s_ctl[4];
   __shared__ int s_cnt;
   const int q = blockIdx.x;
-  ShardSrc src{ids, scores, counts, n_shards, nq, stride, q};
+  const int64_t pitch_ids = pitch ? pitch : (int64_t)nq * stride * 8;
+  const int64_t pitch_cnt = pitch ? pitch : (int64_t)nq * 4;
+  ShardSrc src{ids, scores, counts, n_shards, nq, stride, q, pitch_ids, pitch_cnt};
   int kk = k[q] < stride ? k[q] : stride;
+  uint64_t xh, xl;
   merge_select_sort_write(src, kk, out_ids + (int64_t)q * stride, out_scores + (int64_t)q * stride, out_counts + q,
-                          s_hi, s_lo, s_hist, s_ctl, &s_cnt, nullptr, 1);
+                          s_hi, s_lo, s_hist, s_ctl, &s_cnt, xh, xl);
   if (threadIdx.x == 0) {
     int m = 0;
-    for (int s = 0; s < n_shards; s++) m += map_sizes[(int64_t)s * nq + q];
+    for (int s = 0; s < n_shards; s++) m += ((const int32_t *)((const char *)map_sizes + s * pitch_cnt))[q];
     out_map_sizes[q] = m;
   }
 }
@@ -411,6 +556,10 @@ __global__ void debug_normalise_kernel(int alg, int n, const double *dot, const 
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = normalise(alg, dot[i], nsq[i], l2norm, lognorm);
 }
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
 hipError_t launch_debug_normalise(int alg, int n, const double *dot, const double *nsq, double l2norm, double lognorm,
                                   double *out, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
@@ -418,10 +567,6 @@ hipError_t launch_debug_normalise(int alg, int n, const double *dot, const doubl
                      lognorm, out);
   return hipGetLastError();
 }
-
-// ---------------------------------------------------------------------------------------------
-// launchers
-// ---------------------------------------------------------------------------------------------
 hipError_t launch_unit_general(const IndexView &ix, const BatchView &b, const GeneralWs &ws, int n_units,
                                hipStream_t stream) {
   if (n_units <= 0) return hipSuccess;
@@ -434,11 +579,11 @@ hipError_t launch_merge(const IndexView &ix, const BatchView &b, const int32_t *
   hipLaunchKernelGGL(merge_kernel, dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
   return hipGetLastError();
 }
-hipError_t launch_merge_shards(int n_shards, int nq, int stride, const int64_t *ids, const double *scores,
+hipError_t launch_merge_shards(int n_shards, int nq, int stride, int64_t pitch, const int64_t *ids, const double *scores,
                                const int32_t *counts, const int32_t *map_sizes, const int32_t *k, int64_t *out_ids,
                                double *out_scores, int32_t *out_counts, int32_t *out_map_sizes, hipStream_t stream) {
   if (nq <= 0) return hipSuccess;
-  hipLaunchKernelGGL(merge_shards_kernel, dim3(nq), dim3(WG), 0, stream, n_shards, nq, stride, ids, scores, counts,
+  hipLaunchKernelGGL(merge_shards_kernel, dim3(nq), dim3(WG), 0, stream, n_shards, nq, stride, pitch, ids, scores, counts,
                      map_sizes, k, out_ids, out_scores, out_counts, out_map_sizes);
   return hipGetLastError();
 }

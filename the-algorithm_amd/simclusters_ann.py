@@ -134,10 +134,14 @@ _PROTOS = {
     "sann_batch_device_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "sann_batch_device_k": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "sann_batch_stats": (C.c_int, [C.c_void_p, C.POINTER(sann_batch_stats_t)]),
+    "sann_batch_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "sann_batch_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "sann_device_synchronize": (C.c_int, [C.c_int32]),
     "sann_batch_destroy": (C.c_int, [C.c_void_p]),
     "sann_get_tweet_candidates": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "sann_debug_normalise": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
-    "sann_merge_shards": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sann_batch_bind_outputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sann_merge_shards": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 
@@ -310,10 +314,23 @@ class QueryBatch:
         _check(load_library().sann_batch_device_results(self._h, *[C.byref(x) for x in p], C.byref(st)))
         return [x.value for x in p], st.value
 
+    def bind_outputs(self, d_ids: int, d_scores: int, d_counts: int, d_map_sizes: int):
+        _check(load_library().sann_batch_bind_outputs(self._h, C.c_void_p(d_ids), C.c_void_p(d_scores),
+                                                      C.c_void_p(d_counts), C.c_void_p(d_map_sizes)))
+
     def device_k(self) -> int:
         p = C.c_void_p()
         _check(load_library().sann_batch_device_k(self._h, C.byref(p)))
         return p.value
+
+    def set_profiling(self, enable: bool = True):
+        _check(load_library().sann_batch_set_profiling(self._h, 1 if enable else 0))
+
+    def kernel_times(self):
+        """(unit kernel ms total, merge kernel ms total, timed runs) since set_profiling."""
+        a, b, n = C.c_double(), C.c_double(), C.c_int32()
+        _check(load_library().sann_batch_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
 
     def stats(self) -> sann_batch_stats_t:
         s = sann_batch_stats_t()
