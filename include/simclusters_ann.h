@@ -167,6 +167,10 @@ int sann_batch_stats(sann_batch_t *batch, sann_batch_stats_t *stats);
  * the elapsed times to running totals.  Resets the totals. */
 int sann_batch_set_profiling(sann_batch_t *batch, int32_t enable);
 int sann_batch_kernel_times(sann_batch_t *batch, double *unit_ms_total, double *merge_ms_total, int32_t *n_runs);
+/* Debug: enable=1 makes the fast unit kernel stamp s_memtime at its phase boundaries into a side
+ * buffer; enable=0 returns the averages (avg16[0] = whole unit, avg16[i] = phase i, shader
+ * clocks, avg16[15] = units counted) and frees the buffer.  Never quote a run timed this way. */
+int sann_debug_phase_cycles(sann_batch_t *batch, int32_t enable, double *avg16);
 /* hipDeviceSynchronize on `device` (for callers that do not link the HIP runtime themselves). */
 int sann_device_synchronize(int32_t device);
 int sann_batch_destroy(sann_batch_t *batch);

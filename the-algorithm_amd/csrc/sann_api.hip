@@ -110,7 +110,7 @@ struct sann_batch {
   DevBuf hdr, scan_row, scan_w, scan_q, desc, d_k;
   std::vector<int32_t> h_scan_q;
   DevBuf cand_key, cand_id, cand_cnt, unit_unique, unit_flags, unit_fb, unit_thr, status, overflow_units;
-  DevBuf out_ids, out_scores, out_counts, out_map_sizes;
+  DevBuf out_ids, out_scores, out_counts, out_map_sizes, prof;
   // caller-bound output buffers (NULL = the batch's own)
   void *bound_ids = nullptr, *bound_scores = nullptr, *bound_counts = nullptr, *bound_map_sizes = nullptr;
   // general path: workspace and candidate lists for the units it (re)runs, grown on demand
@@ -162,6 +162,7 @@ struct sann_batch {
     b.out_counts = bound_counts ? (int32_t *)bound_counts : out_counts.as<int32_t>();
     b.out_map_sizes = bound_map_sizes ? (int32_t *)bound_map_sizes : out_map_sizes.as<int32_t>();
     b.stride = stride;
+    b.prof = prof.as<unsigned long long>();
     return b;
   }
 };
@@ -459,15 +460,14 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
     double est_max = 0.0;
     for (double e : unit_est) est_max = std::max(est_max, e);
     const double need = est_max * 1.25 + 32.0;
-    int ucap = 256;
-    while (ucap < 2048 && (double)ucap < need) ucap <<= 1;
+    static const int kCaps[] = {256, 512, 768, 1024, 1536, 2048};  // workgroup size x postings per thread
+    int ucap = 2048;
+    for (int c : kCaps)
+      if ((double)c >= need) { ucap = c; break; }
+    if (const char *ov = getenv("SANN_UNIT_CAP")) ucap = atoi(ov);  // tuning / test override
     b->fast.unit_capacity = ucap;
     b->fast.k_local = 0;
-    // per-unit emission capacity: 3 x the k_local of the largest k, 32-aligned, at most 1024
-    double share = (double)kmax / ix->P;
-    int kl = (int)std::min<double>(kmax, share + 6.0 * std::sqrt(share) + 8.0);
-    int cap = ((3 * kl + 32 + 31) / 32) * 32;
-    b->cap = std::max(64, std::min(cap, 1024));
+    b->cap = FAST_SCAP;  // a fast unit emits at most its survivor list
     const char *force = getenv("SANN_FORCE_GENERAL");
     b->use_fast = !(force && force[0] == '1');
   }
@@ -725,6 +725,34 @@ int sann_batch_kernel_times(sann_batch_t *b, double *unit_ms_total, double *merg
   if (unit_ms_total) *unit_ms_total = b->unit_ms_total;
   if (merge_ms_total) *merge_ms_total = b->merge_ms_total;
   if (n_runs) *n_runs = b->timed_runs;
+  return SANN_OK;
+}
+
+int sann_debug_phase_cycles(sann_batch_t *b, int32_t enable, double *avg16) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  if (enable) {
+    if (!b->prof.p) {
+      HIP_TRY(b->prof.alloc((size_t)std::max(b->n_units, 1) * 16 * 8));
+      HIP_TRY(hipMemset(b->prof.p, 0, b->prof.bytes));
+    }
+    return SANN_OK;
+  }
+  if (!b->prof.p || !avg16) return fail(SANN_EINVAL, "phase profiling was not enabled");
+  std::vector<unsigned long long> h((size_t)b->n_units * 16);
+  HIP_TRY(hipMemcpy(h.data(), b->prof.p, h.size() * 8, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16; i++) avg16[i] = 0.0;
+  int n = 0;
+  for (int u = 0; u < b->n_units; u++) {
+    const unsigned long long *s = &h[(size_t)u * 16];
+    if (s[0] == 0 || s[8] == 0) continue;
+    for (int i = 1; i <= 8; i++) avg16[i] += (double)(s[i] - s[i - 1]);
+    avg16[0] += (double)(s[8] - s[0]);
+    n++;
+  }
+  for (int i = 0; i < 16; i++) avg16[i] = n ? avg16[i] / n : 0.0;
+  avg16[15] = n;
+  HIP_TRY(b->prof.alloc(0));
   return SANN_OK;
 }
 

@@ -84,6 +84,8 @@ struct BatchView {
   int32_t *out_counts;      // [nq]
   int32_t *out_map_sizes;   // [nq]
   int32_t stride;
+  // debug only: per-unit s_memtime stamps at phase boundaries ([n_units*16]); NULL in normal runs
+  unsigned long long *prof;
 };
 
 // Workspace of the general (global-memory table) path, one region per listed unit.

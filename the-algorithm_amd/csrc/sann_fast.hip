@@ -10,27 +10,32 @@
 //               descriptors -> postings.
 //
 // unit_fast_kernel   one workgroup = one unit; the unit's postings live in REGISTERS (U per
-//               thread), LDS holds only a 64-Kbit presence bitmap and small side tables:
+//               thread).  The kernel is instruction-bound, not memory-bound (PMC: ~2 VMEM reads per
+//               wave), so everything is arranged to spend few instructions per posting:
 //   1. descriptors  coalesced read of the unit's (start, len) row; exclusive scan -> flat index
 //   2. gather       flat posting index -> (cluster, position) by binary search over the scan; one
 //                   16-B global load per posting, consecutive lanes = consecutive postings of a
 //                   sub-list; age window and source-tweet filters (:90-91)
 //   3. duplicates   a tweet can sit in several scanned clusters (all its postings are in this unit
-//                   by construction of the partition hash).  Each posting sets bit hash(id) in the
-//                   bitmap; finding the bit already set flags the id as "possibly seen before".
-//                   Flagged ids (true duplicates and a few hash collisions) are matched against
-//                   every thread's registers; real groups are summed by one thread in cluster
-//                   order, so fp64 sums follow the reference's accumulation order (:83-100)
-//                   whatever the thread timing.  Unflagged postings need no LDS traffic at all.
-//   4. finalise     (dot, nsq) -> score (:111-119), `>= minScore` (:125), monotone 64-bit key
-//   5. threshold    MSB-first radix histogram over the keys from the highest bit in which the
-//                   unit's keys differ, stopping once "everything >= this digit" is between k_local
-//                   and cap entries
-//   6. emit         all candidates with key >= threshold (an exact upper set of the unit) and the
-//                   threshold itself, so that the merge can prove the global top-k exact.
+//                   by construction of the partition hash).  Each posting ORs two hash bits into
+//                   one 64-bit word of a blocked Bloom filter with ONE LDS atomic; finding both
+//                   already set flags the id as "possibly seen before".  Flagged ids (true
+//                   duplicates plus a few false positives) are matched against every thread's
+//                   registers; real groups are summed by one thread in cluster order, so fp64 sums
+//                   follow the reference's accumulation order (:83-100) whatever the timing.
+//   4. pre-filter   every live candidate gets an APPROXIMATE fp32 score (a few instructions); an
+//                   MSB-first radix histogram over the 32-bit keys, started at the highest bit in
+//                   which the unit's keys differ, finds a cut tau with between k_local and SCAP
+//                   candidates above it.  |approx/exact - 1| <= EPS, so every candidate below the
+//                   cut has exact score < theta = tau * (1 + 2 EPS).
+//   5. exact        the survivors (tens, out of hundreds) are compacted into LDS and only they
+//                   get the exact fp64 normalisation (:111-119, two divisions and a square root),
+//                   `>= minScore` (:125), and the monotone 64-bit key
+//   6. emit         survivors with exact key >= key(theta): an exact upper set of the unit, plus
+//                   key(theta) so that the merge can prove the global top-k exact.
 //
-// Units that do not fit (too many clusters / postings / flagged ids, or an unresolvable tie
-// group) flag UNIT_OVERFLOW and are re-run by unit_general_kernel.
+// Units that do not fit (too many clusters / postings / flagged ids, scores outside the fp32
+// range, an unresolvable tie group) flag UNIT_OVERFLOW and are re-run by unit_general_kernel.
 #include <hip/hip_runtime.h>
 
 #include "sann_device.h"
@@ -40,10 +45,10 @@
 
 namespace sann {
 
-constexpr int NSCAN_MAX = 128;  // scanned clusters a fast unit can describe
-constexpr int LCAP = 64;        // flagged ids per unit
-constexpr int MCAP = 192;       // postings matching a flagged id per unit
-constexpr int BM_WORDS = 2048;  // 65536-bit presence bitmap
+constexpr int NSCAN_MAX = 128;   // scanned clusters a fast unit can describe
+constexpr int MCAP = 128;        // postings that may belong to a multi-cluster tweet, per unit
+constexpr int BLOOM_WORDS = 512; // 64-bit words of the blocked Bloom filter (32 Kbit)
+constexpr float APPROX_EPS = 4e-6f;  // bound on |approx/exact - 1| of the fp32 pre-filter (actual < 1e-6)
 
 __device__ inline double normalise_f(int alg, double dot, double nsq, double l2norm, double lognorm) {
   switch (alg) {
@@ -88,56 +93,63 @@ __global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, in
   b.desc[2 * o + 1] = len;
 }
 
-enum { CTL_NFLAG = 0, CTL_NM, CTL_UNIQ, CTL_NVALID, CTL_CNT, CTL_SEL_D, CTL_SEL_A, CTL_SEL_B };
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions on the VALU (DPP), result valid in every lane after the readlane
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp_u32(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ inline uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, dpp_u32<0xB1, 0xf>(0u, v));   // quad_perm [1,0,3,2]
+  v = max(v, dpp_u32<0x4E, 0xf>(0u, v));   // quad_perm [2,3,0,1]
+  v = max(v, dpp_u32<0x124, 0xf>(0u, v));  // row_ror 4
+  v = max(v, dpp_u32<0x128, 0xf>(0u, v));  // row_ror 8
+  v = max(v, dpp_u32<0x142, 0xa>(0u, v));  // row_bcast 15 -> rows 1,3
+  v = max(v, dpp_u32<0x143, 0xc>(0u, v));  // row_bcast 31 -> rows 2,3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ inline uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
 
-__device__ inline unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    unsigned long long o = __shfl_xor(v, off, 64);
-    v = o < v ? o : v;
-  }
-  return v;
-}
-__device__ inline unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    unsigned long long o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
-  }
-  return v;
-}
-__device__ inline int wave_sum_i32(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+enum {
+  CTL_NFLAG = 0, CTL_NM, CTL_LIVE, CTL_NSURV, CTL_CNT, CTL_SEL_D, CTL_SEL_A, CTL_SEL_B, CTL_BAD, CTL_KMIN, CTL_KMAX,
+  CTL_N
+};
 
 template <int WG, int U>
-__global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor) {
-  __shared__ uint32_t s_bm[BM_WORDS];
+__global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
+  constexpr int SCAP = FAST_SCAP;
+  __shared__ unsigned long long s_bloom[BLOOM_WORDS];
   __shared__ uint32_t s_begin[NSCAN_MAX];
   __shared__ uint32_t s_pre[NSCAN_MAX + 1];
   __shared__ uint32_t s_len[NSCAN_MAX];
   __shared__ double s_w[NSCAN_MAX];
-  __shared__ unsigned long long s_L[LCAP];
-  __shared__ uint16_t s_Mf[MCAP], s_Mseq[MCAP];
-  __shared__ double s_Msc[MCAP];
-  __shared__ double s_gdot[LCAP], s_gnsq[LCAP];
-  __shared__ int s_gsize[LCAP], s_grep[LCAP];
+  __shared__ float s_w32[NSCAN_MAX];
+  __shared__ unsigned long long s_fbloom[BLOOM_WORDS];
+  __shared__ long long s_Mid[MCAP];
+  __shared__ int s_Mseq[MCAP], s_Mrole[MCAP];
+  __shared__ double s_Msc[MCAP], s_Mdot[MCAP], s_Mnsq[MCAP];
+  __shared__ long long s_sid[SCAP];
+  __shared__ double s_sdot[SCAP], s_snsq[SCAP];
   __shared__ unsigned s_hist[256];
-  __shared__ int s_ctl[8];
-  __shared__ unsigned long long s_minmax[2];
+  __shared__ int s_ctl[CTL_N];
 
   const int tid = threadIdx.x;
-  const int unit = blockIdx.x;
-  const int q = unit >> ix.log2P;
-  const int p = unit & (ix.P - 1);
+  // XCD-aware mapping: consecutive blocks go to different XCDs (round robin over 8), so give all
+  // P units of a query the same blockIdx % 8: they then share one L2 for the query's postings.
+  const int blk = blockIdx.x;
+  const int x = blk & 7, r = blk >> 3;
+  const int p = r & (ix.P - 1);
+  const int q = ((r >> ix.log2P) << 3) + x;
+  if (q >= b.nq) return;
+  const int unit = q * ix.P + p;
   const QueryHdr h = b.hdr[q];
+#define STAMP(i) do { if (b.prof && tid == 0) b.prof[(int64_t)unit * 16 + (i)] = (unsigned long long)clock64(); } while (0)
+  STAMP(0);
 
   // ---- 0. clear ----------------------------------------------------------------------------
-  if (tid < 8) s_ctl[tid] = 0;
-  if (tid == 0) { s_minmax[0] = ~0ull; s_minmax[1] = 0ull; }
-  for (int i = tid; i < BM_WORDS; i += WG) s_bm[i] = 0;
+  if (tid < CTL_N) s_ctl[tid] = (tid == CTL_KMIN) ? -1 : 0;
+  for (int i = tid; i < BLOOM_WORDS; i += WG) { s_bloom[i] = 0ull; s_fbloom[i] = 0ull; }
   for (int i = tid; i <= NSCAN_MAX; i += WG) s_pre[i] = 0xffffffffu;
 
   bool overflow = h.n_scan > NSCAN_MAX;  // uniform
@@ -146,96 +158,115 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
     const uint32_t *d = b.desc + 2 * ((int64_t)h.scan_begin * ix.P + (int64_t)p * h.n_scan);
     for (int c = tid; c < h.n_scan; c += WG) {
       const uint2 v = *reinterpret_cast<const uint2 *>(d + 2 * c);
+      const double w = b.scan_w[h.scan_begin + c];
       s_begin[c] = v.x;
       s_len[c] = v.y;
-      s_w[c] = b.scan_w[h.scan_begin + c];
+      s_w[c] = w;
+      s_w32[c] = (float)w;
     }
   }
   __syncthreads();
   if (!overflow && tid < 64) {
     const int lane = tid;
-    uint32_t a0 = (2 * lane < h.n_scan) ? s_len[2 * lane] : 0;
-    uint32_t a1 = (2 * lane + 1 < h.n_scan) ? s_len[2 * lane + 1] : 0;
-    uint32_t s = a0 + a1, incl = s;
+    const uint32_t a0 = (2 * lane < h.n_scan) ? s_len[2 * lane] : 0;
+    const uint32_t a1 = (2 * lane + 1 < h.n_scan) ? s_len[2 * lane + 1] : 0;
+    const uint32_t s = a0 + a1;
+    uint32_t incl = s;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      uint32_t t = __shfl_up(incl, off, 64);
+      const uint32_t t = __shfl_up(incl, off, 64);
       if (lane >= off) incl += t;
     }
-    uint32_t excl = incl - s;
+    const uint32_t excl = incl - s;
     if (2 * lane <= h.n_scan) s_pre[2 * lane] = excl;
     if (2 * lane + 1 <= h.n_scan) s_pre[2 * lane + 1] = excl + a0;
   }
   __syncthreads();
+  STAMP(1);  // descriptors + scan done
   const uint32_t T = overflow ? 0u : s_pre[h.n_scan];
   if (!overflow && T > (uint32_t)(WG * U)) overflow = true;
 
   // ---- 2. gather (postings stay in registers) -------------------------------------------------
   long long id[U];
-  double sc[U];     // posting score, later the candidate's monotone key bits
-  int seq[U];       // cluster sequence number; -1 = no posting / filtered / consumed
+  double sc[U];  // posting score
+  int seq[U];    // cluster sequence number; bit 16 = group representative; < 0 = no candidate here
+  int live = 0;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    seq[u] = -1;
+    id[u] = 0;
+    sc[u] = 0.0;
+  }
   if (!overflow) {
     Posting pst[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const uint32_t j = (uint32_t)(u * WG + tid);
-      int c = 0;
-#pragma unroll
-      for (int step = NSCAN_MAX / 2; step >= 1; step >>= 1) {
-        const int t = c + step;
-        if (s_pre[t] <= j) c = t;  // entries past n_scan are 0xffffffff
-      }
-      seq[u] = (j < T) ? c : -1;
       pst[u].id = 0;
       pst[u].score = 0.0;
-      if (j < T) pst[u] = ix.postings[s_begin[c] + (j - s_pre[c])];
+      if ((uint32_t)(u * WG) < T) {  // uniform: skip register slots the unit does not reach
+        const uint32_t j = (uint32_t)(u * WG + tid);
+        int c = 0;
+#pragma unroll
+        for (int step = NSCAN_MAX / 2; step >= 1; step >>= 1) {
+          const int t = c + step;
+          if (s_pre[t] <= j) c = t;  // entries past n_scan are 0xffffffff
+        }
+        seq[u] = (j < T) ? c : -1;
+        if (j < T) pst[u] = ix.postings[s_begin[c] + (j - s_pre[c])];
+      }
     }
+    STAMP(2);  // posting loads issued
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      // NB: written as selects, not `seq[u] = -1; continue;` -- hipcc (ROCm 7.2) mis-structurised
-      // that form and dropped the -1 for postings outside the age window.
-      const bool have = seq[u] >= 0;
-      id[u] = have ? pst[u].id : 0;
-      sc[u] = have ? pst[u].score : 0.0;
-      const bool excluded = h.excl_enabled != 0 && id[u] == h.src_excl;  // :90
-      const bool in_window = id[u] >= h.earliest && id[u] <= h.latest;   // :91
-      const bool keep = have && !excluded && in_window;
-      seq[u] = keep ? seq[u] : -1;
-      if (keep) {
-        // ---- 3a. presence bitmap -------------------------------------------------------------
-        const uint32_t hb = table_hash(id[u], 16);
-        const uint32_t bit = 1u << (hb & 31);
-        const uint32_t old = atomicOr(&s_bm[hb >> 5], bit);
-        if (old & bit) {
-          const int f = atomicAdd(&s_ctl[CTL_NFLAG], 1);
-          if (f < LCAP) s_L[f] = (unsigned long long)id[u];
+      if ((uint32_t)(u * WG) < T) {
+        // NB: selects, not `seq[u] = -1; continue;` -- hipcc (ROCm 7.2) mis-structurised that form
+        // and dropped the -1 for postings outside the age window.
+        const bool have = seq[u] >= 0;
+        id[u] = pst[u].id;
+        sc[u] = pst[u].score;
+        const bool excluded = h.excl_enabled != 0 && id[u] == h.src_excl;  // :90
+        const bool in_window = id[u] >= h.earliest && id[u] <= h.latest;   // :91
+        const bool keep = have && !excluded && in_window;
+        seq[u] = keep ? seq[u] : -1;
+        live += __popcll(__ballot(keep));  // wave count, identical in all lanes
+        if (keep) {
+          // ---- 3a. blocked Bloom filter: two bits of one 64-bit word, one atomic --------------
+          const uint32_t hsh = table_hash(id[u], 21);  // 9 bits word, 6 + 6 bits positions
+          const unsigned long long bits = (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63));
+          const unsigned long long old = atomicOr(&s_bloom[hsh >> 12], bits);
+          if ((old & bits) == bits) {
+            // possibly seen before: mark the id's bits in the (sparse) "flagged" filter
+            atomicOr(&s_fbloom[hsh >> 12], bits);
+            s_ctl[CTL_NFLAG] = 1;
+          }
         }
       }
     }
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; u++) seq[u] = -1;
+    if ((tid & 63) == 0 && live) atomicAdd(&s_ctl[CTL_LIVE], live);
   }
   __syncthreads();
-  const int nflag = s_ctl[CTL_NFLAG];
-  if (nflag > LCAP) overflow = true;
+  STAMP(3);  // postings arrived, filtered, bloom done
 
   // ---- 3b. resolve flagged ids ------------------------------------------------------------------
-  int consumed = 0;
-  if (!overflow && nflag > 0) {
-    int gf[U];
+  // Every posting whose bits are all set in the flagged filter (the flagged posting itself, the
+  // earlier postings of the same tweet, and a few hash collisions) joins the match list M; one
+  // thread per M entry then settles its group by comparing ids inside M only.
+  if (!overflow && s_ctl[CTL_NFLAG] != 0) {
+    int mi[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      gf[u] = -1;
-      if (seq[u] >= 0)
-        for (int f = 0; f < nflag; f++)
-          if (s_L[f] == (unsigned long long)id[u]) { gf[u] = f; break; }  // smallest f = canonical group
-      if (gf[u] >= 0) {
-        const int m = atomicAdd(&s_ctl[CTL_NM], 1);
-        if (m < MCAP) {
-          s_Mf[m] = (uint16_t)gf[u];
-          s_Mseq[m] = (uint16_t)seq[u];
-          s_Msc[m] = sc[u];
+      mi[u] = -1;
+      if (seq[u] >= 0) {
+        const uint32_t hsh = table_hash(id[u], 21);
+        const unsigned long long bits = (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63));
+        if ((s_fbloom[hsh >> 12] & bits) == bits) {
+          const int m = atomicAdd(&s_ctl[CTL_NM], 1);
+          mi[u] = m;
+          if (m < MCAP) {
+            s_Mid[m] = id[u];
+            s_Mseq[m] = seq[u];
+            s_Msc[m] = sc[u];
+          }
         }
       }
     }
@@ -244,42 +275,184 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
     if (nm > MCAP) {
       overflow = true;
     } else {
-      for (int f = tid; f < nflag; f += WG) {
-        int cnt = 0, rep = 0x7fffffff;
-        for (int m = 0; m < nm; m++)
-          if (s_Mf[m] == f) { cnt++; rep = s_Mseq[m] < rep ? s_Mseq[m] : rep; }
-        double dot = 0.0, nsq = 0.0;
-        if (cnt >= 2) {
-          int last = -1;
-          for (int r = 0; r < cnt; r++) {  // ascending cluster sequence
-            int best = 0x7fffffff;
-            double bs = 0.0;
-            for (int m = 0; m < nm; m++)
-              if (s_Mf[m] == f) {
-                const int se = s_Mseq[m];
-                if (se > last && se < best) { best = se; bs = s_Msc[m]; }
+      if (nm > 64) {
+        // large match list (duplicate-heavy corpus): one thread per entry, ids compared inside M
+        for (int m = tid; m < nm; m += WG) {
+          const long long my = s_Mid[m];
+          const int myseq = s_Mseq[m];
+          int cnt = 0, rep = myseq;
+          for (int e2 = 0; e2 < nm; e2++) {
+            const bool same = s_Mid[e2] == my;
+            const int se = s_Mseq[e2];
+            cnt += same ? 1 : 0;
+            rep = (same && se < rep) ? se : rep;
+          }
+          int role = 0;
+          if (cnt >= 2) {
+            role = 2;
+            if (myseq == rep) {
+              double dot = 0.0, nsq = 0.0;
+              int last = -1;
+              for (int rr = 0; rr < cnt; rr++) {  // ascending cluster sequence
+                int best = 0x7fffffff;
+                double bs = 0.0;
+                for (int e2 = 0; e2 < nm; e2++) {
+                  const int se = s_Mseq[e2];
+                  if (s_Mid[e2] == my && se > last && se < best) { best = se; bs = s_Msc[e2]; }
+                }
+                dot = dot + bs * s_w[best];  // :92-94
+                nsq = nsq + bs * bs;         // :95-96
+                last = best;
               }
+              s_Mdot[m] = dot;
+              s_Mnsq[m] = nsq;
+              role = 1;
+            }
+          }
+          s_Mrole[m] = role;
+        }
+      } else if (tid < 64) {
+        // One wave settles M.  Sort the 32-bit keys (hash24(id) << 8 | m) so that postings of the
+        // same tweet become adjacent, then every run leader handles its (tiny) group.
+        const int lane = tid;
+        uint32_t key = 0xffffffffu;
+        if (lane < nm) {
+          const long long idm = s_Mid[lane];
+          key = (table_hash(idm, 24) << 8) | (uint32_t)lane;
+        }
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+          for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t other = __shfl_xor(key, j, 64);
+            const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+            key = (lower == up) ? (key < other ? key : other) : (key > other ? key : other);
+          }
+        }
+        const uint32_t prev = __shfl_up(key, 1, 64);
+        const bool valid = key != 0xffffffffu;
+        const bool leader = valid && (lane == 0 || (prev >> 8) != (key >> 8));
+        const int m0 = (int)(key & 0xffu);
+        // leaders walk their run (runs are 1-3 long; > 8 or a hash collision -> general path)
+        int mem[8];
+        int cnt = leader ? 1 : 0;
+        mem[0] = m0;
+        bool clash = false;
+#pragma unroll
+        for (int rr = 1; rr < 8; rr++) {
+          const uint32_t nxt = __shfl_down(key, rr, 64);
+          const bool cont = leader && cnt == rr && lane + rr < 64 && nxt != 0xffffffffu && (nxt >> 8) == (key >> 8);
+          mem[rr] = cont ? (int)(nxt & 0xffu) : 0;
+          cnt += cont ? 1 : 0;
+        }
+        {
+          const uint32_t nxt8 = __shfl_down(key, 8, 64);
+          if (leader && cnt == 8 && lane + 8 < 64 && nxt8 != 0xffffffffu && (nxt8 >> 8) == (key >> 8)) clash = true;
+        }
+        if (leader && cnt >= 2) {
+          const long long my = s_Mid[m0];
+          int sq[8];
+          double sv[8];
+#pragma unroll
+          for (int rr = 0; rr < 8; rr++) {
+            sq[rr] = 0x7fffffff;
+            sv[rr] = 0.0;
+            if (rr < cnt) {
+              if (s_Mid[mem[rr]] != my) clash = true;  // 24-bit hash collision between different tweets
+              sq[rr] = s_Mseq[mem[rr]];
+              sv[rr] = s_Msc[mem[rr]];
+            }
+          }
+          // ordered accumulation: repeatedly take the smallest remaining cluster sequence
+          double dot = 0.0, nsq = 0.0;
+          int rep = 0;
+          int last = -1;
+          for (int t2 = 0; t2 < cnt; t2++) {
+            int best = 0x7fffffff, bi = 0;
+#pragma unroll
+            for (int rr = 0; rr < 8; rr++)
+              if (sq[rr] > last && sq[rr] < best) { best = sq[rr]; bi = rr; }
+            double bs = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < 8; rr++) bs = (rr == bi) ? sv[rr] : bs;
+            if (t2 == 0) rep = bi;
             dot = dot + bs * s_w[best];  // :92-94
             nsq = nsq + bs * bs;         // :95-96
             last = best;
           }
+#pragma unroll
+          for (int rr = 0; rr < 8; rr++)
+            if (rr < cnt) {
+              const int mm = mem[rr];
+              s_Mrole[mm] = (rr == rep) ? 1 : 2;  // 1 = carries the group's sums, 2 = folded away
+              if (rr == rep) { s_Mdot[mm] = dot; s_Mnsq[mm] = nsq; }
+            }
+        } else if (leader) {
+          s_Mrole[m0] = 0;  // on its own (Bloom false positive)
         }
-        s_gsize[f] = cnt;
-        s_grep[f] = rep;
-        s_gdot[f] = dot;
-        s_gnsq[f] = nsq;
+        if (__ballot(clash) != 0ull && lane == 0) s_ctl[CTL_BAD] = 1;
       }
       __syncthreads();
+      int folded = 0;
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const bool grouped = seq[u] >= 0 && gf[u] >= 0 && s_gsize[gf[u] >= 0 ? gf[u] : 0] >= 2;
-        const bool is_rep = grouped && seq[u] == s_grep[gf[u] >= 0 ? gf[u] : 0];
-        // representative: carries the group's sums; the others are folded into it
-        seq[u] = grouped ? (is_rep ? (0x10000 | gf[u]) : -1) : seq[u];
-        consumed += (grouped && !is_rep) ? 1 : 0;
+        const int role = mi[u] >= 0 ? s_Mrole[mi[u]] : 0;
+        // representative: carries the group's sums (bit 16 + its M index); the others fold into it
+        seq[u] = role == 1 ? (0x10000 | mi[u]) : (role == 2 ? -1 : seq[u]);
+        folded += __popcll(__ballot(role == 2));
       }
+      if ((tid & 63) == 0 && folded) atomicSub(&s_ctl[CTL_LIVE], folded);
+      __syncthreads();
     }
   }
+
+  STAMP(4);  // duplicates resolved
+  // ---- 4. approximate fp32 scores and the cut ------------------------------------------------------
+  uint32_t k32[U];
+  {
+    const float invl2 = (float)(1.0 / h.l2norm), invln = (float)(1.0 / h.lognorm);
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      k32[u] = 0;
+      if ((uint32_t)(u * WG) < T && !overflow) {
+        const bool lv = seq[u] >= 0;
+        float d32, n32;
+        if (lv && (seq[u] & 0x10000)) {
+          d32 = (float)s_Mdot[seq[u] & 0xffff];
+          n32 = (float)s_Mnsq[seq[u] & 0xffff];
+        } else {
+          const float s32 = (float)sc[u];
+          d32 = s32 * s_w32[lv ? (seq[u] & 0xffff) : 0];
+          n32 = s32 * s32;
+        }
+        float a;
+        switch (h.alg) {
+          case 2: a = d32 * invl2 * __builtin_amdgcn_rsqf(n32); break;
+          case 4: a = d32 * __builtin_amdgcn_rsqf(n32); break;
+          case 3: a = d32 * invln * __builtin_amdgcn_rcpf(log1pf(n32)); break;
+          case 1: a = d32; break;
+          default: a = 0.f; break;
+        }
+        // the fp32 shortcut is only trusted for ordinary positive magnitudes
+        bad = bad || (lv && !(a > 1e-30f && a < 1e30f && n32 > 1e-30f && n32 < 1e30f));
+        const uint32_t k = lv ? (__float_as_uint(a) | 0x80000000u) : 0u;
+        k32[u] = k;
+        kmin = lv && k < kmin ? k : kmin;
+        kmax = lv && k > kmax ? k : kmax;
+      }
+    }
+    const uint32_t wmin = wave_min_u32(kmin), wmax = wave_max_u32(kmax);
+    const bool wbad = __ballot(bad) != 0ull;
+    if ((tid & 63) == 0) {
+      atomicMin((unsigned *)&s_ctl[CTL_KMIN], wmin);
+      atomicMax((unsigned *)&s_ctl[CTL_KMAX], wmax);
+      if (wbad) s_ctl[CTL_BAD] = 1;
+    }
+  }
+  __syncthreads();
+  if (s_ctl[CTL_BAD]) overflow = true;
 
   if (overflow) {
     if (tid == 0) {
@@ -294,109 +467,59 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
     return;
   }
 
-  // ---- 4. finalise (registers only) ---------------------------------------------------------------
-  int uniq = 0, nval = 0;
-  unsigned long long kmin = ~0ull, kmax = 0ull;
-#pragma unroll
-  for (int u = 0; u < U; u++) {
-    const bool live = seq[u] >= 0;
-    if (live) {
-      uniq++;
-      double dot, nsq;
-      if (seq[u] & 0x10000) {
-        dot = s_gdot[seq[u] & 0xffff];
-        nsq = s_gnsq[seq[u] & 0xffff];
-      } else {
-        dot = 0.0 + sc[u] * s_w[seq[u]];  // getOrElse(tweetId, 0.0) + score * sourceClusterScore
-        nsq = 0.0 + sc[u] * sc[u];
-      }
-      const double v = normalise_f(h.alg, dot, nsq, h.l2norm, h.lognorm);
-      const bool cand = v >= h.min_score;  // :125 (false for NaN)
-      const unsigned long long key = score_key(v);
-      sc[u] = cand ? bits_f64(key) : sc[u];
-      nval += cand ? 1 : 0;
-      kmin = (cand && key < kmin) ? key : kmin;
-      kmax = (cand && key > kmax) ? key : kmax;
-      // a non-candidate still counted in candidateScoresMap.size above
-      seq[u] = cand ? seq[u] : -2;
-    }
-  }
-  {
-    const int wu = wave_sum_i32(uniq), wv = wave_sum_i32(nval);
-    const unsigned long long wmin = wave_min_u64(kmin), wmax = wave_max_u64(kmax);
-    if ((tid & 63) == 0) {
-      if (wu) atomicAdd(&s_ctl[CTL_UNIQ], wu);
-      if (wv) {
-        atomicAdd(&s_ctl[CTL_NVALID], wv);
-        atomicMin(&s_minmax[0], wmin);
-        atomicMax(&s_minmax[1], wmax);
-      }
-    }
-  }
-  __syncthreads();
-  const int n_valid = s_ctl[CTL_NVALID];
-  const int cap = b.cap;
-
-  // ---- 5. threshold ---------------------------------------------------------------------------------
+  STAMP(5);  // approximate scores + min/max
+  const int n_live = s_ctl[CTL_LIVE];
   int kl;
   {
     const float share = (float)h.k / (float)ix.P;
     kl = (int)(share + 6.0f * sqrtf(share) + 8.0f);
     if (kl < k_local_floor) kl = k_local_floor;
     if (kl > h.k) kl = h.k;
-    if (kl > cap) kl = cap;
+    if (kl > SCAP - 32) kl = SCAP - 32;
   }
-  unsigned long long thr = 0;
+  uint32_t tau = 0;  // survivors: k32 >= tau
   bool give_up = false;
-  const int emit_all = cap < kl + kl / 2 + 16 ? cap : kl + kl / 2 + 16;
-  if (n_valid > emit_all) {
-    const unsigned long long gmin = s_minmax[0], gmax = s_minmax[1];
-    const unsigned long long diff = gmin ^ gmax;
-    int shift = 0, width = 0;
-    unsigned long long prefix = gmax;
-    bool done = false;
+  const int keep_all = SCAP < kl + kl / 2 + 16 ? SCAP : kl + kl / 2 + 16;
+  if (n_live > keep_all) {
+    const uint32_t gmin = (uint32_t)s_ctl[CTL_KMIN], gmax = (uint32_t)s_ctl[CTL_KMAX];
+    const uint32_t diff = gmin ^ gmax;
     if (diff == 0) {
-      give_up = n_valid > cap;  // every score identical: cannot cut by score
-      done = true;
+      give_up = true;  // every approximate score identical and too many of them
     } else {
-      const int hbit = 63 - __clzll((long long)diff);
-      shift = hbit - 7 < 0 ? 0 : hbit - 7;
-      width = hbit - shift + 1;
-      prefix = (hbit == 63) ? 0ull : (gmax >> (hbit + 1)) << (hbit + 1);
-    }
-    int need = kl, budget = cap;
-    while (!done) {
-      for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
-      __syncthreads();
-      const unsigned long long hi_mask = (shift + width >= 64) ? 0ull : (~0ull << (shift + width));
+      const int hbit = 31 - __clz((int)diff);
+      int shift = hbit - 7 < 0 ? 0 : hbit - 7;
+      int width = hbit - shift + 1;
+      uint32_t prefix = (hbit == 31) ? 0u : (gmax >> (hbit + 1)) << (hbit + 1);
+      int need = kl, budget = SCAP;
+      for (;;) {
+        for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
+        __syncthreads();
+        const uint32_t hi_mask = (shift + width >= 32) ? 0u : (~0u << (shift + width));
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        if (seq[u] >= 0) {
-          const unsigned long long key = f64_bits(sc[u]);
-          if ((key & hi_mask) == (prefix & hi_mask))
-            atomicAdd(&s_hist[(unsigned)((key >> shift) & ((1u << width) - 1))], 1u);
+        for (int u = 0; u < U; u++) {
+          const uint32_t k = k32[u];
+          if (k != 0u && (k & hi_mask) == (prefix & hi_mask)) atomicAdd(&s_hist[(k >> shift) & ((1u << width) - 1)], 1u);
         }
+        __syncthreads();
+        if (tid < 64) wave_find_digit(s_hist, need, &s_ctl[CTL_SEL_D]);  // writes D, A, B
+        __syncthreads();
+        const int d = s_ctl[CTL_SEL_D], A = s_ctl[CTL_SEL_A], B = s_ctl[CTL_SEL_B];
+        prefix |= (uint32_t)d << shift;
+        bool stop = false;
+        if (A + B <= budget) stop = true;
+        else if (shift == 0) { give_up = true; stop = true; }  // too many identical approximations
+        else {
+          need -= A;
+          budget -= A;
+          const int ns = shift - 8 < 0 ? 0 : shift - 8;
+          width = shift - ns;
+          shift = ns;
+        }
+        __syncthreads();
+        if (stop) break;
       }
-      __syncthreads();
-      if (tid < 64) wave_find_digit(s_hist, need, &s_ctl[CTL_SEL_D]);  // writes D, A, B
-      __syncthreads();
-      const int d = s_ctl[CTL_SEL_D], A = s_ctl[CTL_SEL_A], B = s_ctl[CTL_SEL_B];
-      prefix |= (unsigned long long)d << shift;
-      if (A + B <= budget) {
-        done = true;
-      } else if (shift == 0) {
-        give_up = true;  // more exactly-equal scores than the unit may emit
-        done = true;
-      } else {
-        need -= A;
-        budget -= A;
-        const int ns = shift - 8 < 0 ? 0 : shift - 8;
-        width = shift - ns;
-        shift = ns;
-      }
-      __syncthreads();
+      tau = prefix;
     }
-    thr = prefix;
   }
   if (give_up) {
     if (tid == 0) {
@@ -411,37 +534,66 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
     return;
   }
 
-  // ---- 6. emit -----------------------------------------------------------------------------------------
-  const int64_t obase = (int64_t)unit * cap;
+  STAMP(6);  // threshold found
+  // ---- 5. compact the survivors with their exact (dot, nsq) --------------------------------------
 #pragma unroll
   for (int u = 0; u < U; u++) {
-    if (seq[u] >= 0) {
-      const unsigned long long key = f64_bits(sc[u]);
-      if (key >= thr) {
-        const int o = atomicAdd(&s_ctl[CTL_CNT], 1);
-        if (o < cap) {
-          b.cand_key[obase + o] = key;
-          b.cand_id[obase + o] = id[u];
-        }
+    if (k32[u] != 0u && k32[u] >= tau) {
+      double dot, nsq;
+      if (seq[u] & 0x10000) {
+        dot = s_Mdot[seq[u] & 0xffff];
+        nsq = s_Mnsq[seq[u] & 0xffff];
+      } else {
+        dot = 0.0 + sc[u] * s_w[seq[u] & 0xffff];  // getOrElse(tweetId, 0.0) + score * sourceClusterScore
+        nsq = 0.0 + sc[u] * sc[u];
+      }
+      const int o = atomicAdd(&s_ctl[CTL_NSURV], 1);
+      if (o < SCAP) {
+        s_sid[o] = id[u];
+        s_sdot[o] = dot;
+        s_snsq[o] = nsq;
       }
     }
   }
   __syncthreads();
+  const int ns = s_ctl[CTL_NSURV] < SCAP ? s_ctl[CTL_NSURV] : SCAP;
+  // theta: every candidate below the cut has approx < tau, hence exact < tau * (1 + 2 EPS)
+  unsigned long long theta_key = 0ull;
+  if (tau != 0u) {
+    const double tau_val = (double)__uint_as_float(tau & 0x7fffffffu);
+    theta_key = score_key(tau_val * (1.0 + 2.0 * (double)APPROX_EPS));
+  }
+
+  STAMP(7);  // survivors compacted
+  // ---- 6. exact scores of the survivors, emit ------------------------------------------------------
+  const int64_t obase = (int64_t)unit * b.cap;
+  for (int i = tid; i < ns; i += WG) {
+    const double v = normalise_f(h.alg, s_sdot[i], s_snsq[i], h.l2norm, h.lognorm);
+    const unsigned long long key = score_key(v);
+    if (v >= h.min_score && key >= theta_key) {  // :125 (false for NaN)
+      const int o = atomicAdd(&s_ctl[CTL_CNT], 1);
+      b.cand_key[obase + o] = key;
+      b.cand_id[obase + o] = s_sid[i];
+    }
+  }
+  __syncthreads();
   if (tid == 0) {
-    const int cnt = s_ctl[CTL_CNT];
-    b.cand_cnt[unit] = cnt < cap ? cnt : cap;
-    b.unit_unique[unit] = s_ctl[CTL_UNIQ];
-    b.unit_flags[unit] = (n_valid > cnt) ? UNIT_TRUNCATED : UNIT_OK;
-    b.unit_thr[2 * (int64_t)unit] = thr;
+    const bool withheld = n_live > ns;  // candidates below the cut were not examined exactly
+    b.cand_cnt[unit] = s_ctl[CTL_CNT];
+    b.unit_unique[unit] = n_live;
+    b.unit_flags[unit] = withheld ? UNIT_TRUNCATED : UNIT_OK;
+    b.unit_thr[2 * (int64_t)unit] = withheld ? theta_key : 0ull;
     b.unit_thr[2 * (int64_t)unit + 1] = 0;
   }
-  (void)consumed;
+  STAMP(8);  // emitted
+#undef STAMP
 }
 
 template <int WG, int U>
-static hipError_t launch_one(const IndexView &ix, const BatchView &b, const FastParams &fp, int n_units,
-                             hipStream_t stream) {
-  hipLaunchKernelGGL((unit_fast_kernel<WG, U>), dim3(n_units), dim3(WG), 0, stream, ix, b, fp.k_local);
+static hipError_t launch_one(const IndexView &ix, const BatchView &b, const FastParams &fp, hipStream_t stream) {
+  const int nq8 = (b.nq + 7) / 8 * 8;
+  const int n_blocks = nq8 * ix.P;
+  hipLaunchKernelGGL((unit_fast_kernel<WG, U>), dim3(n_blocks), dim3(WG), 0, stream, ix, b, fp.k_local, n_blocks);
   return hipGetLastError();
 }
 
@@ -456,11 +608,14 @@ hipError_t launch_desc(const IndexView &ix, const BatchView &b, int total_scan, 
 hipError_t launch_unit_fast(const IndexView &ix, const BatchView &b, const FastParams &fp, int n_units,
                             hipStream_t stream) {
   if (n_units <= 0) return hipSuccess;
+  if (b.cap < FAST_SCAP) return hipErrorInvalidValue;
   switch (fp.unit_capacity) {
-    case 256: return launch_one<64, 4>(ix, b, fp, n_units, stream);
-    case 512: return launch_one<128, 4>(ix, b, fp, n_units, stream);
-    case 1024: return launch_one<256, 4>(ix, b, fp, n_units, stream);
-    case 2048: return launch_one<256, 8>(ix, b, fp, n_units, stream);
+    case 256: return launch_one<64, 4>(ix, b, fp, stream);
+    case 512: return launch_one<128, 4>(ix, b, fp, stream);
+    case 768: return launch_one<256, 3>(ix, b, fp, stream);
+    case 1024: return launch_one<256, 4>(ix, b, fp, stream);
+    case 1536: return launch_one<256, 6>(ix, b, fp, stream);
+    case 2048: return launch_one<256, 8>(ix, b, fp, stream);
     default: return hipErrorInvalidValue;
   }
 }

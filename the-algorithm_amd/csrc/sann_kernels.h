@@ -19,6 +19,7 @@ hipError_t launch_debug_normalise(int alg, int n, const double *dot, const doubl
 
 // LDS fast path (sann_fast.hip).  Returns hipErrorInvalidValue when the configuration cannot
 // run on the fast path at all (the caller then uses the general path for every unit).
+constexpr int FAST_SCAP = 160;  // candidates a fast unit examines exactly and may emit (BatchView.cap)
 struct FastParams {
   int unit_capacity;  // postings one unit holds in registers (workgroup size x postings per thread)
   int k_local;        // floor on the entries a unit must offer before it may withhold the rest

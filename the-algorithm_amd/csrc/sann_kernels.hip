@@ -417,7 +417,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
         int shift = hbit - 7 < 0 ? 0 : hbit - 7;
         int width = hbit - shift + 1;
         prefix = (hbit == 63) ? 0ull : (gmax >> (hbit + 1)) << (hbit + 1);
-        int need = h.k, budget = KMAX;
+        int need = h.k, budget = h.k <= 448 ? 512 : KMAX;  // sort 512 entries when that is enough
         for (;;) {
           for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
           __syncthreads();

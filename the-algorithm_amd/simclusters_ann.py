@@ -137,6 +137,7 @@ _PROTOS = {
     "sann_batch_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "sann_batch_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "sann_device_synchronize": (C.c_int, [C.c_int32]),
+    "sann_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "sann_batch_destroy": (C.c_int, [C.c_void_p]),
     "sann_get_tweet_candidates": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "sann_debug_normalise": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),

@@ -1,0 +1,30 @@
+"""Debug: average shader clocks per phase of the fast unit kernel on the bench workload."""
+import ctypes as C
+import os
+import sys
+
+os.environ.setdefault("SANN_NO_TORCH", "1")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+pkg = ge.load_package()
+lib = pkg.load_library()
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+co = pkg.corpus.make_corpus(T)
+offs, cids, scs = pkg.corpus.make_queries(1024)
+index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=P)
+cfg = pkg.SimClustersANNConfig(maxNumResults=400, annAlgorithm=pkg.ScoringAlgorithm.CosineSimilarity)
+qb = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=co.now_ms)
+for _ in range(3):
+    qb.run(); qb.finish()
+assert lib.sann_debug_phase_cycles(qb._h, 1, None) == 0
+qb.run(); qb.finish()
+avg = (C.c_double * 16)()
+assert lib.sann_debug_phase_cycles(qb._h, 0, avg) == 0
+names = ["total", "desc+scan", "issue loads", "wait loads+filter+bloom", "dup resolve", "approx+minmax", "threshold",
+         "compact", "exact+emit"]
+print("P", P, "units counted", int(avg[15]))
+for i, n in enumerate(names):
+    print(f"  {n:28s} {avg[i]:10.0f} clk")
