@@ -37,7 +37,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tweets", type=int, default=int(os.environ.get("SANN_BENCH_TWEETS", 1_000_000)))
+    ap.add_argument("--tweets", type=int, default=int(os.environ.get("SANN_BENCH_TWEETS", 100_000_000)))
+    ap.add_argument("--corpus", default="device", choices=["device", "numpy"],
+                    help="device: generated + indexed on the GPU (any size); numpy: host generator (<= a few M tweets)")
     ap.add_argument("--queries-per-gpu", type=int, default=1024)
     ap.add_argument("--alg", default="cosine", choices=["cosine", "logcosine", "dot"])
     ap.add_argument("--partitions", type=int, default=0)
@@ -74,16 +76,32 @@ def main():
 
     # ---- synthetic corpus + queries; identical on every rank ---------------------
     t0 = time.time()
-    co = pkg.corpus.make_corpus(args.tweets)
     nq = args.queries_per_gpu * world
     offs, cids, scs = pkg.corpus.make_queries(nq)
+    now_ms = pkg.corpus.NOW_MS
+    if args.corpus == "device":
+        index = pkg.ClusterTweetIndex.synthetic(args.tweets, pkg.corpus.N_CLUSTERS, seed=pkg.corpus.CORPUS_SEED,
+                                                index_cap=2000, now_ms=now_ms, device=local_rank,
+                                                n_partitions=args.partitions, shard_id=rank, n_shards=world)
+        co = None
+    else:
+        co = pkg.corpus.make_corpus(args.tweets)
+        index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, device=local_rank,
+                                      n_partitions=args.partitions, shard_id=rank, n_shards=world)
     t_corpus = time.time() - t0
-    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, device=local_rank,
-                                  n_partitions=args.partitions, shard_id=rank, n_shards=world)
+
+    def host_lists(n_queries):
+        """CSR posting lists (as the reference's store returns them) covering the first n queries."""
+        if co is not None:
+            return co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores
+        if world > 1:
+            raise RuntimeError("host export of a sharded device index is not supported")
+        return index.export_lists(cids[:offs[n_queries]])
+
     # cr-mixer default config with maxNumResults = 400 (SURVEY 8d)
     cfg = pkg.SimClustersANNConfig(maxNumResults=400, minScore=0.0, maxTopTweetsPerCluster=800, maxScanClusters=50,
                                    maxTweetCandidateAgeHours=24, minTweetCandidateAgeHours=0, annAlgorithm=alg)
-    qb = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=co.now_ms)
+    qb = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=now_ms)
     stride = qb.stride
     stream = 0
 
@@ -154,32 +172,35 @@ def main():
 
     # ---- parity spot check against the oracle (outside the timed region) -----------------------
     oracle = ge.load_oracle()
-    n_check = min(args.check_queries, nq)
+    n_check = min(args.check_queries, nq) if (co is not None or world == 1) else 0
     exact = 0
-    for q in range(n_check):
-        o_ids, o_sc, o_msz = oracle.sann_query(cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]], None, cfg, co.now_ms,
-                                               co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores)
-        ok = (counts[q] == len(o_ids) and msz[q] == o_msz and np.array_equal(ids[q, :counts[q]], o_ids)
-              and np.array_equal(scores[q, :counts[q]].view(np.int64), o_sc.view(np.int64)))
-        exact += int(ok)
-    recall_parity = exact / max(n_check, 1)
+    if n_check:
+        L = host_lists(n_check)
+        for q in range(n_check):
+            o_ids, o_sc, o_msz = oracle.sann_query(cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]], None, cfg, now_ms, *L)
+            ok = (counts[q] == len(o_ids) and msz[q] == o_msz and np.array_equal(ids[q, :counts[q]], o_ids)
+                  and np.array_equal(scores[q, :counts[q]].view(np.int64), o_sc.view(np.int64)))
+            exact += int(ok)
+    recall_parity = exact / n_check if n_check else None
 
     # ---- CPU baseline: the C restatement of the Scala path on the host cores, bounded sample ---
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and (co is not None or world == 1):
         cores = os.cpu_count() or 1
-        o_i = np.zeros((nq, 1000), np.int64)
-        o_s = np.zeros((nq, 1000), np.float64)
-        o_c = np.zeros(nq, np.int32)
-        probe = min(nq, 4 * cores)
-        sec = oracle.baseline_run(0, cores, offs[:probe + 1], cids, scs, cfg, co.now_ms, co.cluster_ids, co.list_offsets,
-                                  co.tweet_ids, co.scores, o_i, o_s, o_c)
-        n_s = int(min(nq, max(probe, args.cpu_seconds / max(sec / probe, 1e-9))))
-        sec = oracle.baseline_run(0, cores, offs[:n_s + 1], cids, scs, cfg, co.now_ms, co.cluster_ids, co.list_offsets,
-                                  co.tweet_ids, co.scores, o_i, o_s, o_c)
-        cpu = {"value": float(o_c[:n_s].sum() / sec), "unit": "candidates/sec", "cores": cores, "kind": "port",
-               "sample": f"{n_s} of the {nq} queries, 'original' semantics (two-map accumulate + full sort), "
-                         f"{sec:.2f} s wall; C restatement of the Scala CPU path, not the JVM"}
+        n_s = min(nq, max(64, 2 * cores))
+        L = host_lists(n_s)
+        o_i = np.zeros((n_s, 1000), np.int64)
+        o_s = np.zeros((n_s, 1000), np.float64)
+        o_c = np.zeros(n_s, np.int32)
+        sec, reps, cands = 0.0, 0, 0
+        while sec < args.cpu_seconds and reps < 10000:
+            sec += oracle.baseline_run(0, cores, offs[:n_s + 1], cids, scs, cfg, now_ms, *L, o_i, o_s, o_c)
+            cands += int(o_c.sum())
+            reps += 1
+        cpu = {"value": cands / sec, "unit": "candidates/sec", "cores": cores, "kind": "port",
+               "sample": f"the first {n_s} of the {nq} queries x {reps} repetitions, 'original' semantics (hash-map "
+                         f"accumulate + full sort), {sec:.1f} s wall on {cores} threads; C restatement of the Scala CPU "
+                         f"path, not the JVM"}
 
     # ---- roofline of the dominant kernel (unit kernel: gather + accumulate + select) -----------
     # algorithmic bytes per launch: sum_q P_q*16 + n*12 + k_out*16
@@ -207,7 +228,8 @@ def main():
                                f"top-400, N=50 M=800 {args.alg}, {'1xMI355X' if world == 1 else f'{world}xMI355X tweet-hash shards + RCCL all-gather merge'}",
                    "queries": nq, "tweets": args.tweets, "clusters": 144428, "k": 400, "max_scan_clusters": 50,
                    "max_top_tweets_per_cluster": 800, "algorithm": args.alg, "index_cap": 2000,
-                   "partitions": index.info().n_partitions, "sharding": "none" if world == 1 else "tweet-hash"},
+                   "partitions": index.info().n_partitions, "sharding": "none" if world == 1 else "tweet-hash",
+                   "corpus": args.corpus, "index_postings": int(index.info().n_postings_total)},
         "queries_per_sec": nq * args.steps / elapsed,
         "postings_per_sec": int(st.postings_scanned) * args.steps / elapsed,
         "recall_at_400_parity": recall_parity,

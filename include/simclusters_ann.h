@@ -116,6 +116,27 @@ const char *sann_version(void);
 int sann_index_build(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
                      const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores,
                      sann_index_t **out);
+/*
+ * Generate the synthetic SimClusters corpus of SURVEY.md section 8(d) on the device and build
+ * the index from it without a host round trip (per-cluster filter -> sort by score descending
+ * -> cap -> partition: the device form of TopKTweetsForClusterReadableStore.scala:211-229).
+ * Cluster ids are 1..n_clusters.  Deterministic in (params, seed); independent of n_partitions
+ * and of the shard split (every shard generates the same corpus and keeps its tweets).
+ */
+typedef struct sann_synth_params {
+  int64_t n_tweets;
+  int64_t now_ms;                 /* tweet ids are Snowflake ids in [now - window, now) */
+  uint64_t seed;
+  int32_t n_clusters;             /* 144428 in the reference (SimclustersAnnWarmupHandler.scala:33) */
+  int32_t index_cap;              /* tweets kept per cluster (2000: simclusters_index_generation/Config.scala:58) */
+  int32_t window_hours;           /* 24 */
+  int32_t max_clusters_per_tweet; /* 50 */
+  float mean_clusters;            /* 25: clusters per tweet ~ min(max, 1 + Geom(1/mean)) */
+  int32_t reserved;
+} sann_synth_params_t;
+int sann_index_build_synthetic(const sann_index_options_t *opts, const sann_synth_params_t *params, sann_index_t **out);
+/* Snowflake id the generator gives tweet t (0 <= t < n_tweets). */
+int64_t sann_synth_tweet_id(int64_t t, int64_t n_tweets, int64_t now_ms, int32_t window_hours);
 int sann_index_info(const sann_index_t *index, sann_index_info_t *info);
 /* Copy one cluster's postings held by this shard back to the host, in list order
  * (cap = capacity of the out arrays; *n receives the number held).  Test / audit hook. */
@@ -171,6 +192,10 @@ int sann_batch_kernel_times(sann_batch_t *batch, double *unit_ms_total, double *
  * buffer; enable=0 returns the averages (avg16[0] = whole unit, avg16[i] = phase i, shader
  * clocks, avg16[15] = units counted) and frees the buffer.  Never quote a run timed this way. */
 int sann_debug_phase_cycles(sann_batch_t *batch, int32_t enable, double *avg16);
+/* Debug: after sann_batch_run + a device sync and BEFORE sann_batch_finish, histogram of why fast
+ * units overflowed: [1] too many scanned clusters, [2] too many postings, [3] too many
+ * multi-cluster tweets, [4] score outside the fp32 pre-filter range / hash clash, [5] tie group. */
+int sann_debug_overflow_reasons(sann_batch_t *batch, int32_t *counts8, int32_t *n_inexact);
 /* hipDeviceSynchronize on `device` (for callers that do not link the HIP runtime themselves). */
 int sann_device_synchronize(int32_t device);
 int sann_batch_destroy(sann_batch_t *batch);

@@ -37,9 +37,25 @@ def zipf_ranks(rng: np.random.Generator, n: int, n_clusters: int) -> np.ndarray:
     return np.clip(r, 1, n_clusters)  # 1-based rank
 
 
+def perm_multiplier(n_clusters: int) -> int:
+    """Multiplier A of the rank -> cluster map `cluster = 1 + (rank * A) % C`, gcd(A, C) = 1.
+    The same rule is used by the device generator (csrc/sann_corpus.hip)."""
+    import math
+
+    a = 2654435761 % n_clusters
+    if a == 0:
+        a = 1
+    while math.gcd(a, n_clusters) != 1:
+        a += 1
+    return a
+
+
 def cluster_permutation(n_clusters: int, seed: int = 7) -> np.ndarray:
-    """rank (1-based, index r-1) -> cluster id in [1, n_clusters]."""
-    return np.random.default_rng(seed).permutation(n_clusters).astype(np.int32) + 1
+    """rank (1-based, index r-1) -> cluster id in [1, n_clusters]; spreads the popular clusters over
+    the id range.  (`seed` is kept for call compatibility; the map is the fixed multiplicative one
+    so that host- and device-generated corpora and the query generator agree on popularity.)"""
+    r = np.arange(1, n_clusters + 1, dtype=np.int64)
+    return (1 + (r * perm_multiplier(n_clusters)) % n_clusters).astype(np.int32)
 
 
 @dataclasses.dataclass

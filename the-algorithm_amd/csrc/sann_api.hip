@@ -20,39 +20,23 @@
 #include <vector>
 
 #include "../../include/simclusters_ann.h"
-#include "sann_device.h"
+#include "sann_host.h"
 #include "sann_kernels.h"
-#include "sann_math.h"
 
 using namespace sann;
 
-namespace {
-
+namespace sann_host {
 thread_local std::string g_err;
-
 int fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
 }
+}  // namespace sann_host
+using sann_host::DevBuf;
+using sann_host::fail;
+using sann_host::g_err;
 
-#define HIP_TRY(expr)                                                                               \
-  do {                                                                                              \
-    hipError_t e_ = (expr);                                                                         \
-    if (e_ != hipSuccess) return fail(SANN_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-  } while (0)
-
-struct DevBuf {
-  void *p = nullptr;
-  size_t bytes = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t n) {
-    if (p) { (void)hipFree(p); p = nullptr; }
-    bytes = n;
-    if (n == 0) return hipSuccess;
-    return hipMalloc(&p, n);
-  }
-  template <class T> T *as() const { return (T *)p; }
-};
+namespace {
 
 constexpr int64_t kSnowflakeEpochMs = 1288834974657ll;  // BQGenerationUtil.scala:150-153
 inline int64_t snowflake_first_id_for(int64_t ms) { return (int64_t)((uint64_t)(ms - kSnowflakeEpochMs) << 22); }
@@ -73,32 +57,6 @@ uint32_t next_pow2_u32(uint64_t x) {
 }
 
 }  // namespace
-
-struct sann_index {
-  int device = 0;
-  int P = 1, log2P = 0, shard_id = 0, n_shards = 1;
-  std::vector<int32_t> cluster_ids;     // ascending; row = position
-  std::vector<uint32_t> h_sub_offsets;  // host copy of the device CSR
-  int64_t n_postings = 0, n_postings_total = 0;
-  int32_t max_list_len = 0;
-  DevBuf postings, ranks, sub_offsets;
-
-  IndexView view() const {
-    IndexView v;
-    v.postings = postings.as<Posting>();
-    v.ranks = ranks.as<uint32_t>();
-    v.sub_offsets = sub_offsets.as<uint32_t>();
-    v.n_rows = (int32_t)cluster_ids.size();
-    v.P = P;
-    v.log2P = log2P;
-    return v;
-  }
-  int row_of(int32_t cluster) const {
-    auto it = std::lower_bound(cluster_ids.begin(), cluster_ids.end(), cluster);
-    if (it == cluster_ids.end() || *it != cluster) return -1;
-    return (int)(it - cluster_ids.begin());
-  }
-};
 
 struct sann_batch {
   sann_index *ix = nullptr;
@@ -753,6 +711,20 @@ int sann_debug_phase_cycles(sann_batch_t *b, int32_t enable, double *avg16) {
   for (int i = 0; i < 16; i++) avg16[i] = n ? avg16[i] / n : 0.0;
   avg16[15] = n;
   HIP_TRY(b->prof.alloc(0));
+  return SANN_OK;
+}
+
+int sann_debug_overflow_reasons(sann_batch_t *b, int32_t *counts8, int32_t *n_inexact) {
+  if (!b || !counts8) return fail(SANN_EINVAL, "NULL argument");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  std::vector<uint32_t> fl((size_t)b->n_units);
+  std::vector<uint64_t> thr((size_t)b->n_units * 2);
+  HIP_TRY(hipMemcpy(fl.data(), b->unit_flags.p, fl.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(thr.data(), b->unit_thr.p, thr.size() * 8, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 8; i++) counts8[i] = 0;
+  for (int u = 0; u < b->n_units; u++)
+    if (fl[(size_t)u] & UNIT_OVERFLOW) counts8[std::min<uint64_t>(thr[(size_t)u * 2 + 1], 7)]++;
+  if (n_inexact) *n_inexact = b->h_status ? b->h_status[1] : 0;
   return SANN_OK;
 }
 

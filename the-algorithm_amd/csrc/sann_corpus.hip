@@ -1,0 +1,391 @@
+// sann_corpus.hip -- synthetic SimClusters corpus generated ON THE DEVICE and built straight into
+// the index layout (same law as the numpy generator in corpus.py, which
+// serves the small test corpora).  A 100M-tweet corpus is ~2.2e9 (tweet, cluster, score) postings;
+// only those that can reach a cluster's top `index_cap` are ever materialised.
+//
+// This is also the device form of the reference's posting-list materialisation
+//   src/scala/com/twitter/simclusters_v2/summingbird/stores/TopKTweetsForClusterReadableStore.scala:211-229
+//   (keep score > 0, sort by score descending, take maxResults)
+// i.e. SURVEY "next" row N1 for the synthetic source: filter -> per-cluster sort -> cap ->
+// partition, without a host round trip.
+//
+// Law (all constants from the reference, see corpus.py):
+//   tweet t:  n_t = min(max_per_tweet, 1 + Geom(1/mean)) distinct clusters, cluster rank
+//             r = floor((C+1)^u) (Zipf s=1 as the log-uniform law), cluster id = 1 + (r*A mod C);
+//             score = max(exp(N(-2,1)), 0.001); id = Snowflake id spread over the window, unique.
+//   cluster c: all its (tweet, score) sorted by (score desc, tweet id asc), first index_cap kept.
+//
+// Pipeline
+//   1. host: expected list length L_c per cluster -> score threshold tau_c such that the
+//      expected number of postings above it is keep_c = min(L_c, 1.3*cap + 100): a posting below
+//      tau_c can only matter if fewer than `cap` postings of c lie above it, which for
+//      Poisson(keep_c) >= 2700 is a > 13 sigma event; clusters with L_c <= keep_c keep everything.
+//   2. gen_kernel: one thread per tweet, counter-based RNG; surviving postings are appended to
+//      their cluster's bucket with one atomicAdd.
+//   3. sort_kernel: one workgroup per cluster, bitonic sort in LDS by (score desc, id asc), cap,
+//      count the survivors per (cluster, partition) for this shard.
+//   4. host: exclusive scan of the (cluster, partition) counts -> sub_offsets.
+//   5. scatter_kernel: stable partition of every sorted list into the index layout.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <new>
+#include <vector>
+
+#include "sann_host.h"
+
+using namespace sann;
+using sann_host::DevBuf;
+using sann_host::fail;
+
+namespace {
+
+constexpr int SORT_MAX = 4096;  // entries a cluster bucket may hold (LDS bitonic capacity)
+
+struct GenParams {
+  int64_t n_tweets;
+  int32_t n_clusters;
+  int32_t max_per_tweet;
+  float inv_log1mp;   // 1 / ln(1 - 1/mean)
+  double log_c1;      // ln(C + 1)
+  uint32_t perm_mul;  // cluster id = 1 + (rank * perm_mul) % C, gcd(perm_mul, C) = 1
+  uint64_t seed;
+  int64_t ms_begin;   // window start (ms since unix epoch)
+  int64_t ms_span;
+};
+
+__device__ inline uint64_t rng(uint64_t seed, uint64_t t, uint32_t k) {
+  return mix64(seed ^ mix64(t * 0x9E3779B97F4A7C15ull + (uint64_t)k * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull));
+}
+__device__ inline double u01(uint64_t x) { return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+
+__host__ __device__ inline int64_t synth_tweet_id(int64_t t, int64_t n_tweets, int64_t ms_begin, int64_t ms_span) {
+  // evenly spread in time; the low 22 bits are a bijection of t's low 22 bits, so ids are unique
+  const int64_t ms = ms_begin + (int64_t)(((__int128)t * ms_span) / n_tweets);
+  return (int64_t)(((uint64_t)(ms - 1288834974657ll) << 22) | (((uint64_t)t * 2654435761ull) & 0x3FFFFFull));
+}
+
+// One thread per tweet.
+__global__ __launch_bounds__(256) void gen_kernel(GenParams g, const float *zthr /*[C+1] by cluster id*/,
+                                                  const uint32_t *bucket_off /*[C+2]*/, uint32_t *cursor /*[C+1]*/,
+                                                  Posting *buckets, unsigned int *overflow_flag) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= g.n_tweets) return;
+  const uint64_t r0 = rng(g.seed, (uint64_t)t, 0);
+  // n_t = min(max, 1 + Geom(p)) : floor(ln(u)/ln(1-p)) failures before the first success
+  int n_t = 1 + (int)(__logf((float)u01(r0)) * g.inv_log1mp);
+  if (n_t > g.max_per_tweet) n_t = g.max_per_tweet;
+  if (n_t < 1) n_t = 1;
+  const int64_t id = synth_tweet_id(t, g.n_tweets, g.ms_begin, g.ms_span);
+  int32_t seen[64];
+  int n_seen = 0;
+  for (int j = 0; j < n_t; j++) {
+    const uint64_t a = rng(g.seed, (uint64_t)t, 1 + 3 * j);
+    // fp64: in fp32 the grid of u * ln(C+1) is coarser than one rank near r = C and the tail
+    // clusters would get visibly uneven mass
+    int r = (int)exp(u01(a) * g.log_c1);
+    r = r < 1 ? 1 : (r > g.n_clusters ? g.n_clusters : r);
+    const int c = 1 + (int)(((uint64_t)(uint32_t)r * g.perm_mul) % (uint32_t)g.n_clusters);
+    bool dup = false;
+    for (int i = 0; i < n_seen; i++) dup = dup || (seen[i] == c);
+    if (dup) continue;  // distinct clusters per tweet: a repeated draw is dropped
+    if (n_seen < 64) seen[n_seen++] = c;
+    // z ~ N(0,1) by Box-Muller; cheap fp32 screen against the cluster's threshold first
+    const double u1 = u01(rng(g.seed, (uint64_t)t, 2 + 3 * j)), u2 = u01(rng(g.seed, (uint64_t)t, 3 + 3 * j));
+    const float zt = zthr[c];
+    const float z32 = sqrtf(-2.0f * __logf((float)u1)) * __cosf(6.2831853f * (float)u2);
+    if (z32 < zt - 0.01f) continue;
+    const double z = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    if (z < (double)zt) continue;
+    double s = exp(-2.0 + z);
+    s = s < 0.001 ? 0.001 : s;
+    const uint32_t o = atomicAdd(&cursor[c], 1u);
+    const uint32_t cap = bucket_off[c + 1] - bucket_off[c];
+    if (o < cap) {
+      Posting p;
+      p.id = id;
+      p.score = s;
+      buckets[bucket_off[c] + o] = p;
+    } else {
+      atomicOr(overflow_flag, 1u);
+    }
+  }
+}
+
+// One workgroup per cluster id c in [1, C]: sort the bucket, cap, count per partition.
+__global__ __launch_bounds__(256) void sort_kernel(int n_clusters, int index_cap, int P, int n_shards, int shard_id,
+                                                   const uint32_t *bucket_off, const uint32_t *cursor, Posting *buckets,
+                                                   uint32_t *kept /*[C+1]*/, uint32_t *cnt_cp /*[C*P]*/) {
+  __shared__ uint64_t s_hi[SORT_MAX], s_lo[SORT_MAX];
+  __shared__ unsigned s_cnt[256];
+  const int c = blockIdx.x + 1;
+  const int tid = threadIdx.x;
+  const uint32_t base = bucket_off[c];
+  uint32_t n = cursor[c];
+  const uint32_t cap = bucket_off[c + 1] - base;
+  if (n > cap) n = cap;
+  int np = 2;
+  while (np < (int)n) np <<= 1;
+  for (int i = tid; i < np; i += 256) {
+    if (i < (int)n) {
+      const Posting p = buckets[base + i];
+      s_hi[i] = score_key(p.score);
+      s_lo[i] = id_key(p.id);
+    } else {
+      s_hi[i] = 0;
+      s_lo[i] = 0;
+    }
+  }
+  for (int i = tid; i < 256; i += 256) s_cnt[i] = 0;
+  __syncthreads();
+  for (int size = 2; size <= np; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (np >> 1); t += 256) {
+        const int i = 2 * t - (t & (stride - 1));
+        const int j = i + stride;
+        const bool desc = ((i & size) == 0);
+        const uint64_t ah = s_hi[i], al = s_lo[i], bh = s_hi[j], bl = s_lo[j];
+        const bool a_lt_b = ah < bh || (ah == bh && al < bl);
+        const bool a_gt_b = ah > bh || (ah == bh && al > bl);
+        if (desc ? a_lt_b : a_gt_b) {
+          s_hi[i] = bh; s_lo[i] = bl;
+          s_hi[j] = ah; s_lo[j] = al;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const uint32_t k = n < (uint32_t)index_cap ? n : (uint32_t)index_cap;
+  for (uint32_t i = tid; i < k; i += 256) {
+    Posting p;
+    p.id = key_id(s_lo[i]);
+    p.score = key_score(s_hi[i]);
+    buckets[base + i] = p;  // rank order
+    const uint64_t h = mix64((uint64_t)p.id);
+    if (tweet_shard(h, (uint32_t)n_shards) == (uint32_t)shard_id) atomicAdd(&s_cnt[tweet_partition(h, (uint32_t)P)], 1u);
+  }
+  __syncthreads();
+  if (tid == 0) kept[c] = k;
+  for (int p = tid; p < P; p += 256) cnt_cp[(int64_t)(c - 1) * P + p] = s_cnt[p];
+}
+
+// One workgroup per cluster: stable partition of the rank-ordered list into the index layout.
+__global__ __launch_bounds__(256) void scatter_kernel(int P, int n_shards, int shard_id, const uint32_t *bucket_off,
+                                                      const uint32_t *kept, const Posting *buckets,
+                                                      const uint32_t *sub_offsets, Posting *postings, uint32_t *ranks) {
+  __shared__ uint8_t s_part[SORT_MAX];  // partition of rank i, 255 = other shard
+  const int c = blockIdx.x + 1;
+  const int tid = threadIdx.x;
+  const uint32_t base = bucket_off[c];
+  const uint32_t k = kept[c];
+  for (uint32_t i = tid; i < k; i += 256) {
+    const uint64_t h = mix64((uint64_t)buckets[base + i].id);
+    s_part[i] = tweet_shard(h, (uint32_t)n_shards) == (uint32_t)shard_id ? (uint8_t)tweet_partition(h, (uint32_t)P) : 255;
+  }
+  __syncthreads();
+  // thread p walks the list in rank order and copies its partition's entries
+  for (int p = tid; p < P; p += 256) {
+    uint32_t o = sub_offsets[(int64_t)(c - 1) * P + p];
+    for (uint32_t i = 0; i < k; i++) {
+      if (s_part[i] == (uint8_t)p) {
+        postings[o] = buckets[base + i];
+        ranks[o] = i;
+        o++;
+      }
+    }
+  }
+}
+
+// inverse normal CDF (Acklam's rational approximation, |rel err| < 1.2e-9)
+double inv_norm_cdf(double p) {
+  static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+                             1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+  static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02,
+                             6.680131188771972e+01, -1.328068155288572e+01};
+  static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00,
+                             -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+  static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00,
+                             3.754408661907416e+00};
+  const double plow = 0.02425, phigh = 1 - plow;
+  if (p < plow) {
+    double q = std::sqrt(-2 * std::log(p));
+    return (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) /
+           ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
+  }
+  if (p > phigh) {
+    double q = std::sqrt(-2 * std::log(1 - p));
+    return -(((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) /
+           ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
+  }
+  double q = p - 0.5, r = q * q;
+  return (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q /
+         (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1);
+}
+
+uint64_t gcd_u64(uint64_t a, uint64_t b) { return b ? gcd_u64(b, a % b) : a; }
+
+}  // namespace
+
+extern "C" {
+
+int sann_index_build_synthetic(const sann_index_options_t *opts, const sann_synth_params_t *sp, sann_index_t **out) {
+  if (!out) return fail(SANN_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (!opts || !sp) return fail(SANN_EINVAL, "NULL argument");
+  const int P = opts->n_partitions == 0 ? 32 : opts->n_partitions;
+  if (P < 1 || P > 128 || (P & (P - 1))) return fail(SANN_EINVAL, "n_partitions must be a power of two in [1,128]");
+  const int n_shards = opts->n_shards <= 0 ? 1 : opts->n_shards;
+  if (opts->shard_id < 0 || opts->shard_id >= n_shards) return fail(SANN_EINVAL, "shard_id out of range");
+  const int C = sp->n_clusters;
+  if (sp->n_tweets < 1 || C < 1 || sp->index_cap < 1) return fail(SANN_EINVAL, "bad synthetic parameters");
+  if (sp->max_clusters_per_tweet < 1 || sp->max_clusters_per_tweet > 64 || !(sp->mean_clusters > 1.0f))
+    return fail(SANN_EINVAL, "bad clusters-per-tweet parameters");
+  const double keep_cap = 1.3 * sp->index_cap + 100.0;
+  if (keep_cap + 8 * std::sqrt(keep_cap) + 32 > SORT_MAX)
+    return fail(SANN_ELIMIT, "index_cap too large for the device builder (max ~2900)");
+
+  // ---- 1. thresholds and bucket capacities -----------------------------------------------------
+  const double p_geo = 1.0 / sp->mean_clusters;
+  // E[min(max, 1+Geom)] = (1 - (1-p)^max) / p
+  const double mean_nt = (1.0 - std::pow(1.0 - p_geo, sp->max_clusters_per_tweet)) / p_geo;
+  const double log_c1 = std::log((double)C + 1.0);
+  uint32_t perm_mul = 2654435761u % (uint32_t)C;
+  if (perm_mul == 0) perm_mul = 1;
+  while (gcd_u64(perm_mul, (uint64_t)C) != 1) perm_mul++;
+  std::vector<float> zthr((size_t)C + 1, -1e30f);
+  std::vector<uint32_t> boff((size_t)C + 2, 0);
+  std::vector<double> expect((size_t)C + 1, 0.0);
+  for (int r = 1; r <= C; r++) {
+    const int c = 1 + (int)(((uint64_t)(uint32_t)r * perm_mul) % (uint32_t)C);
+    const double pr = std::log(1.0 + 1.0 / r) / log_c1;
+    const double L = (double)sp->n_tweets * mean_nt * pr;
+    double keep = L;
+    if (L > keep_cap) {
+      keep = keep_cap;
+      zthr[(size_t)c] = (float)inv_norm_cdf(1.0 - keep_cap / L);
+    }
+    expect[(size_t)c] = keep;
+  }
+  uint64_t run = 0;
+  for (int c = 1; c <= C; c++) {
+    boff[(size_t)c] = (uint32_t)run;
+    // the fp32 threshold is rounded, so allow a little more than Poisson noise
+    const double cap = expect[(size_t)c] * 1.02 + 8.0 * std::sqrt(expect[(size_t)c] + 1.0) + 32.0;
+    run += (uint64_t)std::min<double>(cap, SORT_MAX);
+    if (run > 0xfffffff0ull) return fail(SANN_ELIMIT, "synthetic corpus too large for one build");
+  }
+  boff[(size_t)C + 1] = (uint32_t)run;
+
+  sann_index *ix = new (std::nothrow) sann_index();
+  if (!ix) return fail(SANN_ENOMEM, "out of host memory");
+  struct Guard { sann_index *p; ~Guard() { delete p; } } guard{ix};
+  ix->device = opts->device;
+  ix->P = P;
+  ix->log2P = 0;
+  while ((1 << ix->log2P) < P) ix->log2P++;
+  ix->shard_id = opts->shard_id;
+  ix->n_shards = n_shards;
+  ix->cluster_ids.resize((size_t)C);
+  for (int c = 1; c <= C; c++) ix->cluster_ids[(size_t)c - 1] = c;
+
+  HIP_TRY(hipSetDevice(ix->device));
+  DevBuf d_zthr, d_boff, d_cursor, d_buckets, d_flag, d_kept, d_cnt;
+  HIP_TRY(d_zthr.alloc(((size_t)C + 1) * 4));
+  HIP_TRY(d_boff.alloc(((size_t)C + 2) * 4));
+  HIP_TRY(d_cursor.alloc(((size_t)C + 1) * 4));
+  HIP_TRY(d_kept.alloc(((size_t)C + 1) * 4));
+  HIP_TRY(d_cnt.alloc((size_t)C * P * 4));
+  HIP_TRY(d_flag.alloc(4));
+  HIP_TRY(d_buckets.alloc(std::max<uint64_t>(run, 1) * sizeof(Posting)));
+  HIP_TRY(hipMemcpy(d_zthr.p, zthr.data(), zthr.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_boff.p, boff.data(), boff.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d_cursor.p, 0, ((size_t)C + 1) * 4));
+  HIP_TRY(hipMemset(d_flag.p, 0, 4));
+
+  // ---- 2. generate --------------------------------------------------------------------------------
+  GenParams g;
+  g.n_tweets = sp->n_tweets;
+  g.n_clusters = C;
+  g.max_per_tweet = sp->max_clusters_per_tweet;
+  g.inv_log1mp = (float)(1.0 / std::log(1.0 - p_geo));
+  g.log_c1 = log_c1;
+  g.perm_mul = perm_mul;
+  g.seed = sp->seed;
+  g.ms_span = (int64_t)sp->window_hours * 3600000ll;
+  g.ms_begin = sp->now_ms - g.ms_span;
+  const int64_t gen_blocks = (sp->n_tweets + 255) / 256;
+  if (gen_blocks > 0x7fffffffll) return fail(SANN_ELIMIT, "too many tweets");
+  hipLaunchKernelGGL(gen_kernel, dim3((unsigned)gen_blocks), dim3(256), 0, 0, g, d_zthr.as<float>(), d_boff.as<uint32_t>(),
+                     d_cursor.as<uint32_t>(), d_buckets.as<Posting>(), d_flag.as<unsigned int>());
+  HIP_TRY(hipGetLastError());
+  unsigned int flag = 0;
+  HIP_TRY(hipMemcpy(&flag, d_flag.p, 4, hipMemcpyDeviceToHost));
+  if (flag) {
+    std::vector<uint32_t> cur((size_t)C + 1);
+    HIP_TRY(hipMemcpy(cur.data(), d_cursor.p, cur.size() * 4, hipMemcpyDeviceToHost));
+    int worst = 1, n_over = 0;
+    double worst_ratio = 0.0;
+    for (int c = 1; c <= C; c++) {
+      const double cap = (double)(boff[(size_t)c + 1] - boff[(size_t)c]);
+      if (cur[(size_t)c] > cap) n_over++;
+      if (cur[(size_t)c] / cap > worst_ratio) { worst_ratio = cur[(size_t)c] / cap; worst = c; }
+    }
+    char msg[256];
+    snprintf(msg, sizeof msg,
+             "synthetic corpus: %d cluster buckets overflowed; worst cluster %d got %u postings for a bucket of %u "
+             "(expected %.0f, z threshold %.3f)",
+             n_over, worst, cur[(size_t)worst], boff[(size_t)worst + 1] - boff[(size_t)worst], expect[(size_t)worst],
+             (double)zthr[(size_t)worst]);
+    return fail(SANN_EINTERNAL, msg);
+  }
+
+  // ---- 3. sort + cap + count ----------------------------------------------------------------------
+  hipLaunchKernelGGL(sort_kernel, dim3((unsigned)C), dim3(256), 0, 0, C, sp->index_cap, P, n_shards, ix->shard_id,
+                     d_boff.as<uint32_t>(), d_cursor.as<uint32_t>(), d_buckets.as<Posting>(), d_kept.as<uint32_t>(),
+                     d_cnt.as<uint32_t>());
+  HIP_TRY(hipGetLastError());
+  std::vector<uint32_t> cnt((size_t)C * P), kept((size_t)C + 1);
+  HIP_TRY(hipMemcpy(cnt.data(), d_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(kept.data(), d_kept.p, kept.size() * 4, hipMemcpyDeviceToHost));
+
+  // ---- 4. offsets -----------------------------------------------------------------------------------
+  ix->h_sub_offsets.resize((size_t)C * P + 1);
+  uint64_t tot = 0;
+  for (size_t i = 0; i < (size_t)C * P; i++) {
+    ix->h_sub_offsets[i] = (uint32_t)tot;
+    tot += cnt[i];
+    if (tot > 0xfffffff0ull) return fail(SANN_ELIMIT, "more than 2^32 postings in one shard");
+  }
+  ix->h_sub_offsets[(size_t)C * P] = (uint32_t)tot;
+  ix->n_postings = (int64_t)tot;
+  int64_t total_all = 0;
+  int32_t max_len = 0;
+  for (int c = 1; c <= C; c++) {
+    total_all += kept[(size_t)c];
+    max_len = std::max<int32_t>(max_len, (int32_t)kept[(size_t)c]);
+  }
+  ix->n_postings_total = total_all;
+  ix->max_list_len = max_len;
+  HIP_TRY(ix->postings.alloc(std::max<uint64_t>(tot, 1) * sizeof(Posting)));
+  HIP_TRY(ix->ranks.alloc(std::max<uint64_t>(tot, 1) * 4));
+  HIP_TRY(ix->sub_offsets.alloc(ix->h_sub_offsets.size() * 4));
+  HIP_TRY(hipMemcpy(ix->sub_offsets.p, ix->h_sub_offsets.data(), ix->h_sub_offsets.size() * 4, hipMemcpyHostToDevice));
+
+  // ---- 5. scatter ------------------------------------------------------------------------------------
+  hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)C), dim3(256), 0, 0, P, n_shards, ix->shard_id, d_boff.as<uint32_t>(),
+                     d_kept.as<uint32_t>(), d_buckets.as<Posting>(), ix->sub_offsets.as<uint32_t>(),
+                     ix->postings.as<Posting>(), ix->ranks.as<uint32_t>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  guard.p = nullptr;
+  *out = ix;
+  return SANN_OK;
+}
+
+int64_t sann_synth_tweet_id(int64_t t, int64_t n_tweets, int64_t now_ms, int32_t window_hours) {
+  const int64_t span = (int64_t)window_hours * 3600000ll;
+  return synth_tweet_id(t, n_tweets, now_ms - span, span);
+}
+
+}  // extern "C"

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
   for (int i = tid; i <= NSCAN_MAX; i += WG) s_pre[i] = 0xffffffffu;
 
   bool overflow = h.n_scan > NSCAN_MAX;  // uniform
+  int why = overflow ? 1 : 0;  // overflow reason (kept in unit_thr[2u+1] for diagnostics)
   // ---- 1. descriptors ----------------------------------------------------------------------
   if (!overflow) {
     const uint32_t *d = b.desc + 2 * ((int64_t)h.scan_begin * ix.P + (int64_t)p * h.n_scan);
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
   __syncthreads();
   STAMP(1);  // descriptors + scan done
   const uint32_t T = overflow ? 0u : s_pre[h.n_scan];
-  if (!overflow && T > (uint32_t)(WG * U)) overflow = true;
+  if (!overflow && T > (uint32_t)(WG * U)) { overflow = true; why = 2; }
 
   // ---- 2. gather (postings stay in registers) -------------------------------------------------
   long long id[U];
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
     const int nm = s_ctl[CTL_NM];
     if (nm > MCAP) {
       overflow = true;
+      why = 3;
     } else {
       if (nm > 64) {
         // large match list (duplicate-heavy corpus): one thread per entry, ids compared inside M
@@ -318,7 +320,8 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
         uint32_t key = 0xffffffffu;
         if (lane < nm) {
           const long long idm = s_Mid[lane];
-          key = (table_hash(idm, 24) << 8) | (uint32_t)lane;
+          // independent of table_hash: M's members were selected for agreeing on table_hash bits
+          key = ((uint32_t)(mix64((uint64_t)idm) >> 40) << 8) | (uint32_t)lane;
         }
 #pragma unroll
         for (int k = 2; k <= 64; k <<= 1) {
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
         } else if (leader) {
           s_Mrole[m0] = 0;  // on its own (Bloom false positive)
         }
-        if (__ballot(clash) != 0ull && lane == 0) s_ctl[CTL_BAD] = 1;
+        if (__ballot(clash) != 0ull && lane == 0) s_ctl[CTL_BAD] = 2;
       }
       __syncthreads();
       int folded = 0;
@@ -448,11 +451,11 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
     if ((tid & 63) == 0) {
       atomicMin((unsigned *)&s_ctl[CTL_KMIN], wmin);
       atomicMax((unsigned *)&s_ctl[CTL_KMAX], wmax);
-      if (wbad) s_ctl[CTL_BAD] = 1;
+      if (wbad) atomicOr(&s_ctl[CTL_BAD], 1);
     }
   }
   __syncthreads();
-  if (s_ctl[CTL_BAD]) overflow = true;
+  if (s_ctl[CTL_BAD] && !overflow) { overflow = true; why = (s_ctl[CTL_BAD] & 2) ? 6 : 4; }
 
   if (overflow) {
     if (tid == 0) {
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
       b.unit_unique[unit] = 0;
       b.unit_flags[unit] = UNIT_OVERFLOW;
       b.unit_thr[2 * (int64_t)unit] = 0;
-      b.unit_thr[2 * (int64_t)unit + 1] = 0;
+      b.unit_thr[2 * (int64_t)unit + 1] = (unsigned long long)why;
       const int o = atomicAdd(&b.status[0], 1);
       b.overflow_units[o] = unit;
     }
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
       b.unit_unique[unit] = 0;
       b.unit_flags[unit] = UNIT_OVERFLOW;
       b.unit_thr[2 * (int64_t)unit] = 0;
-      b.unit_thr[2 * (int64_t)unit + 1] = 0;
+      b.unit_thr[2 * (int64_t)unit + 1] = 5ull;
       const int o = atomicAdd(&b.status[0], 1);
       b.overflow_units[o] = unit;
     }

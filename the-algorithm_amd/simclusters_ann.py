@@ -73,6 +73,20 @@ class sann_index_info_t(C.Structure):
     ]
 
 
+class sann_synth_params_t(C.Structure):
+    _fields_ = [
+        ("n_tweets", C.c_int64),
+        ("now_ms", C.c_int64),
+        ("seed", C.c_uint64),
+        ("n_clusters", C.c_int32),
+        ("index_cap", C.c_int32),
+        ("window_hours", C.c_int32),
+        ("max_clusters_per_tweet", C.c_int32),
+        ("mean_clusters", C.c_float),
+        ("reserved", C.c_int32),
+    ]
+
+
 class sann_batch_stats_t(C.Structure):
     _fields_ = [
         ("postings_scanned", C.c_int64),
@@ -124,6 +138,8 @@ _PROTOS = {
     "sann_last_error": (C.c_char_p, []),
     "sann_version": (C.c_char_p, []),
     "sann_index_build": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "sann_index_build_synthetic": (C.c_int, [C.POINTER(sann_index_options_t), C.POINTER(sann_synth_params_t), C.POINTER(C.c_void_p)]),
+    "sann_synth_tweet_id": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     "sann_index_info": (C.c_int, [C.c_void_p, C.POINTER(sann_index_info_t)]),
     "sann_index_get_list": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "sann_index_destroy": (C.c_int, [C.c_void_p]),
@@ -137,6 +153,7 @@ _PROTOS = {
     "sann_batch_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "sann_batch_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "sann_device_synchronize": (C.c_int, [C.c_int32]),
+    "sann_debug_overflow_reasons": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sann_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "sann_batch_destroy": (C.c_int, [C.c_void_p]),
     "sann_get_tweet_candidates": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -209,6 +226,40 @@ class ClusterTweetIndex:
                                     _ptr(tweet_ids), _ptr(scores), C.byref(h)))
         self._h = h
         self.device = device
+
+    @classmethod
+    def synthetic(cls, n_tweets: int, n_clusters: int = 144_428, *, seed: int = 20260104, index_cap: int = 2000,
+                  now_ms: int = 1_700_000_000_000, window_hours: int = 24, mean_clusters: float = 25.0,
+                  max_clusters_per_tweet: int = 50, device: int = 0, n_partitions: int = 0, shard_id: int = 0,
+                  n_shards: int = 1) -> "ClusterTweetIndex":
+        """Synthetic corpus generated and indexed on the device."""
+        lib = load_library()
+        self = cls.__new__(cls)
+        opts = sann_index_options_t(device, n_partitions, shard_id, n_shards)
+        sp = sann_synth_params_t(n_tweets, now_ms, seed, n_clusters, index_cap, window_hours, max_clusters_per_tweet,
+                                 mean_clusters, 0)
+        h = C.c_void_p()
+        _check(lib.sann_index_build_synthetic(C.byref(opts), C.byref(sp), C.byref(h)))
+        self._h = h
+        self.device = device
+        self.cluster_ids = np.arange(1, n_clusters + 1, dtype=np.int32)
+        self.list_offsets = None
+        self.now_ms = now_ms
+        return self
+
+    def export_lists(self, cluster_ids):
+        """CSR (cluster_ids, list_offsets, tweet_ids, scores) of the given clusters, copied back from
+        the device in list order: what the oracle needs to answer a query on this index."""
+        cids = np.unique(np.asarray(cluster_ids, np.int32))
+        offs = [0]
+        ts, ss = [], []
+        for c in cids:
+            t, s, _r = self.get_list(int(c))
+            ts.append(t)
+            ss.append(s)
+            offs.append(offs[-1] + len(t))
+        return (cids, np.array(offs, np.int64), np.concatenate(ts) if ts else np.empty(0, np.int64),
+                np.concatenate(ss) if ss else np.empty(0, np.float64))
 
     @classmethod
     def from_map(cls, cluster_tweets: Mapping[int, Sequence[Tuple[int, float]]], **kw) -> "ClusterTweetIndex":
