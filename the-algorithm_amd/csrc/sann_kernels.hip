@@ -29,7 +29,7 @@ namespace sann {
 
 constexpr int WG = 256;
 constexpr int KMAX = 1024;       // >= MaxNumResultsUpperBound (1000), ApproximateCosineSimilarity.scala:41
-constexpr int MERGE_LDS = 4096;  // entries the merge can sort in LDS
+constexpr int MERGE_LDS = 3072;  // entries the merge can stage in LDS
 
 // ---------------------------------------------------------------------------------------------
 // normalisation, ApproximateCosineSimilarity.scala:111-119
@@ -287,23 +287,6 @@ __device__ inline void unit_list(const BatchView &b, int64_t unit, const uint64_
   }
 }
 
-struct UnitListSrc {
-  const BatchView *b;
-  int64_t unit0;  // first unit of the query
-  int P, capmax;
-  __device__ int size() const { return P * capmax; }
-  __device__ bool get(int i, uint64_t &hi, uint64_t &lo) const {
-    int u = i / capmax, j = i - u * capmax;
-    if (j >= b->cand_cnt[unit0 + u]) return false;
-    const uint64_t *key;
-    const int64_t *id;
-    unit_list(*b, unit0 + u, key, id);
-    hi = key[j];
-    lo = id_key(id[j]);
-    return true;
-  }
-};
-
 // Select (radix) + sort (LDS bitonic) + write.  Returns the k-th key through xk (0,0 = none).
 template <class Src>
 __device__ void merge_select_sort_write(const Src &src, int k, int64_t *out_ids, double *out_scores, int32_t *out_count,
@@ -336,6 +319,85 @@ __device__ void merge_select_sort_write(const Src &src, int k, int64_t *out_ids,
   if (tid == 0) *out_count = cnt;
 }
 
+// 128-bit radix threshold over LDS arrays: finds thr with  need <= #{key >= thr} <= budget
+// (requires n >= need; keys are unique).  Scores first, from the highest bit in which they
+// differ; if more than `budget` entries tie on the whole score key it continues into the id
+// key, which always separates.  s_ctl: 4 ints, s_mm: 2 u64, s_hist: 256 uints (all LDS).
+__device__ void lds_radix_cut(const uint64_t *hi, const uint64_t *lo, int n, int need, int budget, unsigned *s_hist,
+                              int *s_ctl, uint64_t *s_mm, uint64_t &thr_hi, uint64_t &thr_lo) {
+  const int tid = threadIdx.x;
+  uint64_t pre_hi = 0, pre_lo = 0;
+  for (int word = 0; word < 2; word++) {
+    // min / max of the active word among the entries still in play
+    uint64_t kmin = ~0ull, kmax = 0ull;
+    for (int i = tid; i < n; i += WG) {
+      if (word == 1 && hi[i] != pre_hi) continue;
+      const uint64_t k = word == 0 ? hi[i] : lo[i];
+      kmin = k < kmin ? k : kmin;
+      kmax = k > kmax ? k : kmax;
+    }
+    if (tid == 0) { s_mm[0] = ~0ull; s_mm[1] = 0ull; }
+    __syncthreads();
+    atomicMin((unsigned long long *)&s_mm[0], (unsigned long long)kmin);
+    atomicMax((unsigned long long *)&s_mm[1], (unsigned long long)kmax);
+    __syncthreads();
+    const uint64_t gmin = s_mm[0], gmax = s_mm[1];
+    const uint64_t diff = gmin ^ gmax;
+    __syncthreads();
+    if (diff == 0) {
+      // every entry in play has the same value in this word
+      if (word == 0) { pre_hi = gmax; continue; }
+      pre_lo = gmax;
+      break;
+    }
+    const int hbit = 63 - __clzll((long long)diff);
+    int shift = hbit - 7 < 0 ? 0 : hbit - 7;
+    int width = hbit - shift + 1;
+    uint64_t prefix = (hbit == 63) ? 0ull : (gmax >> (hbit + 1)) << (hbit + 1);
+    bool settled = false;
+    for (;;) {
+      for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
+      __syncthreads();
+      const uint64_t hi_mask = (shift + width >= 64) ? 0ull : (~0ull << (shift + width));
+      for (int i = tid; i < n; i += WG) {
+        if (word == 1 && hi[i] != pre_hi) continue;
+        const uint64_t k = word == 0 ? hi[i] : lo[i];
+        if ((k & hi_mask) == (prefix & hi_mask)) atomicAdd(&s_hist[(unsigned)((k >> shift) & ((1u << width) - 1))], 1u);
+      }
+      __syncthreads();
+      if (tid < 64) wave_find_digit(s_hist, need, &s_ctl[1]);
+      __syncthreads();
+      const int d = s_ctl[1], A = s_ctl[2], B = s_ctl[3];
+      prefix |= (uint64_t)d << shift;
+      bool stop = false;
+      if (A + B <= budget) {
+        settled = true;  // everything >= prefix is between need and budget entries
+        stop = true;
+      } else {
+        // digit d alone holds too many: the A entries above it are in, recurse into d
+        need -= A;
+        budget -= A;
+        if (shift == 0) {
+          stop = true;  // they share this whole word: continue in the next word
+        } else {
+          const int ns = shift - 8 < 0 ? 0 : shift - 8;
+          width = shift - ns;
+          shift = ns;
+        }
+      }
+      __syncthreads();
+      if (stop) break;
+    }
+    if (word == 0) pre_hi = prefix; else pre_lo = prefix;
+    if (settled) break;
+  }
+  thr_hi = pre_hi;
+  thr_lo = pre_lo;
+}
+
+// One workgroup per query.  Chunked tournament: the current best (<= KMAX entries, in s_hi2) plus
+// as many unit lists as fit are staged in LDS, cut to the entries that can still be in the
+// top-k, and compacted back; after the last chunk the survivors are sorted.
 __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, const int32_t *query_list) {
   __shared__ uint64_t s_hi[MERGE_LDS], s_lo[MERGE_LDS];
   __shared__ uint64_t s_hi2[KMAX], s_lo2[KMAX];
@@ -350,6 +412,8 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   const QueryHdr h = b.hdr[q];
   const int P = ix.P;  // <= 256
   const int64_t unit0 = (int64_t)q * P;
+  const int k = h.k;
+  const int budget = k <= 448 ? 512 : KMAX;  // survivors kept between chunks / sorted at the end
 
   // offsets of the unit lists in a flat index space (P <= 256: one thread per unit, wave scans)
   {
@@ -369,113 +433,72 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
     if (tid == WG - 1) s_off[WG] = wbase + incl;
     __syncthreads();
   }
-  const int total = s_off[WG];
-  uint64_t xk_hi = 0, xk_lo = 0;
   int64_t *out_ids = b.out_ids + (int64_t)q * b.stride;
   double *out_scores = b.out_scores + (int64_t)q * b.stride;
 
-  if (total <= MERGE_LDS) {
-    // stage every entry in LDS
-    for (int i = tid; i < total; i += WG) {
-      int u = 0;
-#pragma unroll
-      for (int step = 128; step >= 1; step >>= 1) {
-        int t = u + step;
-        if (t < WG && s_off[t] <= i) u = t;
-      }
-      const uint64_t *key;
-      const int64_t *id;
-      unit_list(b, unit0 + u, key, id);
-      const int j = i - s_off[u];
-      s_hi[i] = key[j];
-      s_lo[i] = id_key(id[j]);
-    }
-    __syncthreads();
-    // cut to the entries that can matter: radix threshold on the score key so that between k
-    // and KMAX entries survive, then sort only those
-    uint64_t *srt_hi = s_hi, *srt_lo = s_lo;
-    int n_sort = total;
-    if (total > h.k + 128 && h.k > 0) {
-      // min / max of the keys
-      uint64_t kmin = ~0ull, kmax = 0ull;
-      for (int i = tid; i < total; i += WG) {
-        const uint64_t k = s_hi[i];
-        kmin = k < kmin ? k : kmin;
-        kmax = k > kmax ? k : kmax;
-      }
-      if (tid == 0) { s_mm[0] = ~0ull; s_mm[1] = 0ull; }
-      __syncthreads();
-      atomicMin((unsigned long long *)&s_mm[0], (unsigned long long)kmin);
-      atomicMax((unsigned long long *)&s_mm[1], (unsigned long long)kmax);
-      __syncthreads();
-      const uint64_t gmin = s_mm[0], gmax = s_mm[1];
-      const uint64_t diff = gmin ^ gmax;
-      uint64_t prefix = 0;
-      bool ok = diff != 0;
-      if (ok) {
-        const int hbit = 63 - __clzll((long long)diff);
-        int shift = hbit - 7 < 0 ? 0 : hbit - 7;
-        int width = hbit - shift + 1;
-        prefix = (hbit == 63) ? 0ull : (gmax >> (hbit + 1)) << (hbit + 1);
-        int need = h.k, budget = h.k <= 448 ? 512 : KMAX;  // sort 512 entries when that is enough
-        for (;;) {
-          for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
-          __syncthreads();
-          const uint64_t hi_mask = (shift + width >= 64) ? 0ull : (~0ull << (shift + width));
-          for (int i = tid; i < total; i += WG) {
-            const uint64_t k = s_hi[i];
-            if ((k & hi_mask) == (prefix & hi_mask)) atomicAdd(&s_hist[(unsigned)((k >> shift) & ((1u << width) - 1))], 1u);
-          }
-          __syncthreads();
-          if (tid < 64) wave_find_digit(s_hist, need, &s_ctl[1]);
-          __syncthreads();
-          const int d = s_ctl[1], A = s_ctl[2], B = s_ctl[3];
-          prefix |= (uint64_t)d << shift;
-          bool stop = false;
-          if (A + B <= budget) stop = true;
-          else if (shift == 0) { ok = false; stop = true; }  // too many exact ties: sort everything
-          else {
-            need -= A; budget -= A;
-            const int ns = shift - 8 < 0 ? 0 : shift - 8;
-            width = shift - ns; shift = ns;
-          }
-          __syncthreads();
-          if (stop) break;
-        }
-      }
-      if (ok) {
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        for (int i = tid; i < total; i += WG) {
-          const uint64_t k = s_hi[i];
-          if (k >= prefix) {
-            const int o = atomicAdd(&s_cnt, 1);
-            s_hi2[o] = k;
-            s_lo2[o] = s_lo[i];
+  int best_n = 0;  // entries currently in s_hi2 / s_lo2
+  int u_begin = 0;
+  while (u_begin < P) {
+    // units [u_begin, u_end) such that best + their entries fit (a single list always fits:
+    // MERGE_LDS - KMAX >= any per-unit capacity)
+    int u_end = u_begin;
+    const int base_off = s_off[u_begin];
+    while (u_end < P && best_n + (s_off[u_end + 1] - base_off) <= MERGE_LDS) u_end++;
+    if (u_end == u_begin) u_end = u_begin + 1;  // cannot happen given the capacities; keeps progress
+    const int n_new = s_off[u_end] - base_off;
+    const int n = best_n + n_new;
+    for (int i = tid; i < best_n; i += WG) { s_hi[i] = s_hi2[i]; s_lo[i] = s_lo2[i]; }
+    {
+      // one wave per unit list: contiguous, coalesced, address-independent loads
+      const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll 4
+      for (int u = u_begin + wave; u < u_end; u += WG / 64) {
+        const int o = best_n + s_off[u] - base_off, m = s_off[u + 1] - s_off[u];
+        if (m > 0) {
+          const uint64_t *key;
+          const int64_t *id;
+          unit_list(b, unit0 + u, key, id);
+          for (int j = lane; j < m; j += 64) {
+            if (o + j < MERGE_LDS) {
+              s_hi[o + j] = key[j];
+              s_lo[o + j] = id_key(id[j]);
+            }
           }
         }
-        __syncthreads();
-        n_sort = s_cnt;
-        srt_hi = s_hi2;
-        srt_lo = s_lo2;
       }
     }
-    const int np = next_pow2(n_sort);
-    for (int i = n_sort + tid; i < np; i += WG) { srt_hi[i] = 0; srt_lo[i] = 0; }
     __syncthreads();
-    bitonic_sort_desc(srt_hi, srt_lo, np);
-    const int cnt = n_sort < h.k ? n_sort : h.k;
+    uint64_t thi = 0, tlo = 0;
+    if (n > budget && k > 0) lds_radix_cut(s_hi, s_lo, n, k, budget, s_hist, s_ctl, s_mm, thi, tlo);
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += WG) {
+      const uint64_t a = s_hi[i], c = s_lo[i];
+      if (k > 0 && key_ge(a, c, thi, tlo)) {
+        const int o = atomicAdd(&s_cnt, 1);
+        if (o < KMAX) { s_hi2[o] = a; s_lo2[o] = c; }
+      }
+    }
+    __syncthreads();
+    best_n = s_cnt < KMAX ? s_cnt : KMAX;
+    u_begin = u_end;
+    __syncthreads();
+  }
+
+  // sort the survivors, keep the first k
+  uint64_t xk_hi = 0, xk_lo = 0;
+  {
+    const int np = next_pow2(best_n);
+    for (int i = best_n + tid; i < np; i += WG) { s_hi2[i] = 0; s_lo2[i] = 0; }
+    __syncthreads();
+    bitonic_sort_desc(s_hi2, s_lo2, np);
+    const int cnt = best_n < k ? best_n : k;
     for (int i = tid; i < cnt; i += WG) {
-      out_ids[i] = key_id(srt_lo[i]);
-      out_scores[i] = key_score(srt_hi[i]);
+      out_ids[i] = key_id(s_lo2[i]);
+      out_scores[i] = key_score(s_hi2[i]);
     }
-    if (cnt == h.k && cnt > 0) { xk_hi = srt_hi[cnt - 1]; xk_lo = srt_lo[cnt - 1]; }
+    if (cnt == k && cnt > 0) { xk_hi = s_hi2[cnt - 1]; xk_lo = s_lo2[cnt - 1]; }
     if (tid == 0) b.out_counts[q] = cnt;
-  } else {
-    const int capmax = b.cap > b.cap2 ? b.cap : b.cap2;
-    UnitListSrc src{&b, unit0, P, capmax};
-    merge_select_sort_write(src, h.k, out_ids, out_scores, b.out_counts + q, s_hi, s_lo, s_hist, s_ctl, &s_cnt, xk_hi,
-                            xk_lo);
   }
   __syncthreads();
   // candidateScoresMap.size (:102) and the exactness proof: every candidate a unit withheld has
@@ -485,7 +508,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   for (int u = tid; u < P; u += WG) {
     const int64_t unit = unit0 + u;
     msz += b.unit_unique[unit];
-    if (h.k > 0 && (b.unit_flags[unit] & UNIT_TRUNCATED)) {
+    if (k > 0 && (b.unit_flags[unit] & UNIT_TRUNCATED)) {
       const uint64_t thi = b.unit_thr[2 * unit], tlo = b.unit_thr[2 * unit + 1];
       if (key_gt(thi, tlo, xk_hi, xk_lo)) inexact = 1;
     }

@@ -11,12 +11,11 @@ import __graft_entry__ as ge  # noqa: E402
 pkg = ge.load_package()
 lib = pkg.load_library()
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-T = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
-co = pkg.corpus.make_corpus(T)
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
 offs, cids, scs = pkg.corpus.make_queries(1024)
-index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=P)
+index = pkg.ClusterTweetIndex.synthetic(T, n_partitions=P)
 cfg = pkg.SimClustersANNConfig(maxNumResults=400, annAlgorithm=pkg.ScoringAlgorithm.CosineSimilarity)
-qb = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=co.now_ms)
+qb = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=pkg.corpus.NOW_MS)
 for _ in range(3):
     qb.run(); qb.finish()
 assert lib.sann_debug_phase_cycles(qb._h, 1, None) == 0
