@@ -65,7 +65,7 @@ struct sann_batch {
   std::vector<int32_t> h_scan_row;
   std::vector<double> h_scan_w;
   std::vector<int32_t> h_k;
-  DevBuf hdr, scan_row, scan_w, scan_q, desc, d_k;
+  DevBuf hdr, scan_row, scan_w, scan_q, desc, unit_T, d_k;
   std::vector<int32_t> h_scan_q;
   DevBuf cand_key, cand_id, cand_cnt, unit_unique, unit_flags, unit_fb, unit_thr, status, overflow_units;
   DevBuf out_ids, out_scores, out_counts, out_map_sizes, prof;
@@ -101,6 +101,7 @@ struct sann_batch {
     b.scan_w = scan_w.as<double>();
     b.scan_q = scan_q.as<int32_t>();
     b.desc = desc.as<uint32_t>();
+    b.unit_T = unit_T.as<int32_t>();
     b.nq = nq;
     b.cap = cap;
     b.cap2 = cap2;
@@ -437,6 +438,7 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
   HIP_TRY(b->scan_w.alloc(std::max<size_t>(b->h_scan_w.size(), 1) * 8));
   HIP_TRY(b->scan_q.alloc(std::max<size_t>(b->h_scan_q.size(), 1) * 4));
   HIP_TRY(b->desc.alloc(std::max<size_t>(b->h_scan_row.size(), 1) * (size_t)ix->P * 8));
+  HIP_TRY(b->unit_T.alloc(nu * 4));
   HIP_TRY(b->d_k.alloc(nqz * 4));
   HIP_TRY(b->cand_key.alloc(nu * (size_t)b->cap * 8));
   HIP_TRY(b->cand_id.alloc(nu * (size_t)b->cap * 8));
@@ -538,7 +540,7 @@ int sann_batch_run(sann_batch_t *b, void *hip_stream) {
   } else {
     if (b->profiling) HIP_TRY(hipEventRecord(b->ev[0], st));
     if (b->use_fast) {
-      hipError_t e = launch_desc(b->ix->view(), b->view(), (int)b->h_scan_row.size(), st);
+      hipError_t e = launch_desc(b->ix->view(), b->view(), b->n_units, st);
       if (e != hipSuccess) return fail(SANN_EDEVICE, std::string("launch_desc: ") + hipGetErrorString(e));
       e = launch_unit_fast(b->ix->view(), b->view(), b->fast, b->n_units, st);
       if (e != hipSuccess) return fail(SANN_EDEVICE, std::string("launch_unit_fast: ") + hipGetErrorString(e));

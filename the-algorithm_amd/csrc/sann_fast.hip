@@ -47,7 +47,8 @@ namespace sann {
 
 constexpr int NSCAN_MAX = 128;   // scanned clusters a fast unit can describe
 constexpr int MCAP = 128;        // postings that may belong to a multi-cluster tweet, per unit
-constexpr int BLOOM_WORDS = 512; // 64-bit words of the blocked Bloom filter (32 Kbit)
+constexpr int BLOOM_WORDS = 1024;  // 64-bit words of the blocked Bloom filter (64 Kbit, 3 bits per posting)
+constexpr int FBLOOM_WORDS = 256;  // the sparse "flagged" filter
 constexpr float APPROX_EPS = 4e-6f;  // bound on |approx/exact - 1| of the fp32 pre-filter (actual < 1e-6)
 
 __device__ inline double normalise_f(int alg, double dot, double nsq, double l2norm, double lognorm) {
@@ -71,26 +72,55 @@ __device__ inline int lower_bound_rank(const uint32_t *a, int n, uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, int total_scan) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int e = t >> ix.log2P;
-  const int p = t & (ix.P - 1);
-  if (e >= total_scan) return;
-  const int q = b.scan_q[e];
+// One WAVE per unit: lane c (and c + 64) resolves cluster c's sub-list, the wave scans the lengths,
+// and the unit kernel later reads (start, exclusive prefix) pairs and the unit's posting count.
+__global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, int n_units) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + wave;
+  if (unit >= n_units) return;
+  const int q = unit >> ix.log2P;
+  const int p = unit & (ix.P - 1);
   const int M = b.hdr[q].M;
   const int scan_begin = b.hdr[q].scan_begin;
   const int n_scan = b.hdr[q].n_scan;
-  const int row = b.scan_row[e];
-  const uint32_t base = ix.sub_offsets[(int64_t)row * ix.P + p];
-  const uint32_t end = ix.sub_offsets[(int64_t)row * ix.P + p + 1];
-  const int n = (int)(end - base);
-  // postings with rank < M are a prefix of the sub-list
-  const uint32_t len = (n > 0 && ix.ranks[base + n - 1] < (uint32_t)M) ? (uint32_t)n
-                                                                     : (uint32_t)lower_bound_rank(ix.ranks + base, n, (uint32_t)M);
-  // unit-major layout: the (q, p) unit reads n_scan consecutive entries
-  const int64_t o = (int64_t)scan_begin * ix.P + (int64_t)p * n_scan + (e - scan_begin);
-  b.desc[2 * o] = base;
-  b.desc[2 * o + 1] = len;
+  if (n_scan > NSCAN_MAX) {  // the unit kernel sends such units to the general path
+    if (lane == 0) b.unit_T[unit] = 0;
+    return;
+  }
+  uint32_t base[2], len[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int c = lane + 64 * r;
+    base[r] = 0;
+    len[r] = 0;
+    if (c < n_scan) {
+      const int row = b.scan_row[scan_begin + c];
+      base[r] = ix.sub_offsets[(int64_t)row * ix.P + p];
+      const uint32_t end = ix.sub_offsets[(int64_t)row * ix.P + p + 1];
+      const int n = (int)(end - base[r]);
+      // postings with rank < M are a prefix of the sub-list
+      len[r] = (n > 0 && ix.ranks[base[r] + n - 1] < (uint32_t)M) ? (uint32_t)n
+                                                                 : (uint32_t)lower_bound_rank(ix.ranks + base[r], n, (uint32_t)M);
+    }
+  }
+  uint32_t incl0 = len[0], incl1 = len[1];
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t0 = __shfl_up(incl0, off, 64), t1 = __shfl_up(incl1, off, 64);
+    if (lane >= off) { incl0 += t0; incl1 += t1; }
+  }
+  const uint32_t total0 = __shfl(incl0, 63, 64), total1 = __shfl(incl1, 63, 64);
+  // unit-major layout: the (q, p) unit reads n_scan consecutive (start, prefix) pairs
+  uint32_t *d = b.desc + 2 * ((int64_t)scan_begin * ix.P + (int64_t)p * n_scan);
+  if (lane < n_scan) {
+    d[2 * lane] = base[0];
+    d[2 * lane + 1] = incl0 - len[0];
+  }
+  if (lane + 64 < n_scan) {
+    d[2 * (lane + 64)] = base[1];
+    d[2 * (lane + 64) + 1] = total0 + incl1 - len[1];
+  }
+  if (lane == 0) b.unit_T[unit] = (int32_t)(total0 + total1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -121,11 +151,11 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
   constexpr int SCAP = FAST_SCAP;
   __shared__ unsigned long long s_bloom[BLOOM_WORDS];
   __shared__ uint32_t s_begin[NSCAN_MAX];
-  __shared__ uint32_t s_pre[NSCAN_MAX + 1];
-  __shared__ uint32_t s_len[NSCAN_MAX];
+  __shared__ uint32_t s_pre[NSCAN_MAX];
+  __shared__ uint8_t s_map[WG * U];  // flat posting index -> cluster sequence number
   __shared__ double s_w[NSCAN_MAX];
   __shared__ float s_w32[NSCAN_MAX];
-  __shared__ unsigned long long s_fbloom[BLOOM_WORDS];
+  __shared__ unsigned long long s_fbloom[FBLOOM_WORDS];
   __shared__ long long s_Mid[MCAP];
   __shared__ int s_Mseq[MCAP], s_Mrole[MCAP];
   __shared__ double s_Msc[MCAP], s_Mdot[MCAP], s_Mnsq[MCAP];
@@ -149,43 +179,30 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
 
   // ---- 0. clear ----------------------------------------------------------------------------
   if (tid < CTL_N) s_ctl[tid] = (tid == CTL_KMIN) ? -1 : 0;
-  for (int i = tid; i < BLOOM_WORDS; i += WG) { s_bloom[i] = 0ull; s_fbloom[i] = 0ull; }
-  for (int i = tid; i <= NSCAN_MAX; i += WG) s_pre[i] = 0xffffffffu;
+  for (int i = tid; i < BLOOM_WORDS; i += WG) s_bloom[i] = 0ull;
+  for (int i = tid; i < FBLOOM_WORDS; i += WG) s_fbloom[i] = 0ull;
 
   bool overflow = h.n_scan > NSCAN_MAX;  // uniform
   int why = overflow ? 1 : 0;  // overflow reason (kept in unit_thr[2u+1] for diagnostics)
   // ---- 1. descriptors ----------------------------------------------------------------------
+  const uint32_t T = overflow ? 0u : (uint32_t)b.unit_T[unit];
+  if (!overflow && T > (uint32_t)(WG * U)) { overflow = true; why = 2; }
   if (!overflow) {
     const uint32_t *d = b.desc + 2 * ((int64_t)h.scan_begin * ix.P + (int64_t)p * h.n_scan);
     for (int c = tid; c < h.n_scan; c += WG) {
       const uint2 v = *reinterpret_cast<const uint2 *>(d + 2 * c);
+      const uint32_t next = (c + 1 < h.n_scan) ? d[2 * (c + 1) + 1] : T;
       const double w = b.scan_w[h.scan_begin + c];
       s_begin[c] = v.x;
-      s_len[c] = v.y;
+      s_pre[c] = v.y;
       s_w[c] = w;
       s_w32[c] = (float)w;
+      // every posting of this cluster records its cluster in the flat map
+      for (uint32_t i = v.y; i < next; i++) s_map[i] = (uint8_t)c;
     }
   }
   __syncthreads();
-  if (!overflow && tid < 64) {
-    const int lane = tid;
-    const uint32_t a0 = (2 * lane < h.n_scan) ? s_len[2 * lane] : 0;
-    const uint32_t a1 = (2 * lane + 1 < h.n_scan) ? s_len[2 * lane + 1] : 0;
-    const uint32_t s = a0 + a1;
-    uint32_t incl = s;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
-    }
-    const uint32_t excl = incl - s;
-    if (2 * lane <= h.n_scan) s_pre[2 * lane] = excl;
-    if (2 * lane + 1 <= h.n_scan) s_pre[2 * lane + 1] = excl + a0;
-  }
-  __syncthreads();
-  STAMP(1);  // descriptors + scan done
-  const uint32_t T = overflow ? 0u : s_pre[h.n_scan];
-  if (!overflow && T > (uint32_t)(WG * U)) { overflow = true; why = 2; }
+  STAMP(1);  // descriptors + map done
 
   // ---- 2. gather (postings stay in registers) -------------------------------------------------
   long long id[U];
@@ -206,12 +223,7 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
       pst[u].score = 0.0;
       if ((uint32_t)(u * WG) < T) {  // uniform: skip register slots the unit does not reach
         const uint32_t j = (uint32_t)(u * WG + tid);
-        int c = 0;
-#pragma unroll
-        for (int step = NSCAN_MAX / 2; step >= 1; step >>= 1) {
-          const int t = c + step;
-          if (s_pre[t] <= j) c = t;  // entries past n_scan are 0xffffffff
-        }
+        const int c = (j < T) ? (int)s_map[j] : 0;
         seq[u] = (j < T) ? c : -1;
         if (j < T) pst[u] = ix.postings[s_begin[c] + (j - s_pre[c])];
       }
@@ -231,13 +243,14 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
         seq[u] = keep ? seq[u] : -1;
         live += __popcll(__ballot(keep));  // wave count, identical in all lanes
         if (keep) {
-          // ---- 3a. blocked Bloom filter: two bits of one 64-bit word, one atomic --------------
-          const uint32_t hsh = table_hash(id[u], 21);  // 9 bits word, 6 + 6 bits positions
-          const unsigned long long bits = (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63));
-          const unsigned long long old = atomicOr(&s_bloom[hsh >> 12], bits);
+          // ---- 3a. blocked Bloom filter: three bits of one 64-bit word, one atomic ------------
+          const uint32_t hsh = table_hash(id[u], 28);  // 10 bits word, 3 x 6 bits positions
+          const unsigned long long bits =
+              (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63)) | (1ull << ((hsh >> 12) & 63));
+          const unsigned long long old = atomicOr(&s_bloom[hsh >> 18], bits);
           if ((old & bits) == bits) {
             // possibly seen before: mark the id's bits in the (sparse) "flagged" filter
-            atomicOr(&s_fbloom[hsh >> 12], bits);
+            atomicOr(&s_fbloom[hsh >> 20], bits);
             s_ctl[CTL_NFLAG] = 1;
           }
         }
@@ -258,9 +271,10 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
     for (int u = 0; u < U; u++) {
       mi[u] = -1;
       if (seq[u] >= 0) {
-        const uint32_t hsh = table_hash(id[u], 21);
-        const unsigned long long bits = (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63));
-        if ((s_fbloom[hsh >> 12] & bits) == bits) {
+        const uint32_t hsh = table_hash(id[u], 28);
+        const unsigned long long bits =
+            (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63)) | (1ull << ((hsh >> 12) & 63));
+        if ((s_fbloom[hsh >> 20] & bits) == bits) {
           const int m = atomicAdd(&s_ctl[CTL_NM], 1);
           mi[u] = m;
           if (m < MCAP) {
@@ -600,10 +614,9 @@ static hipError_t launch_one(const IndexView &ix, const BatchView &b, const Fast
   return hipGetLastError();
 }
 
-hipError_t launch_desc(const IndexView &ix, const BatchView &b, int total_scan, hipStream_t stream) {
-  const int64_t n = (int64_t)total_scan * ix.P;
-  if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(desc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ix, b, total_scan);
+hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, hipStream_t stream) {
+  if (n_units <= 0) return hipSuccess;
+  hipLaunchKernelGGL(desc_kernel, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, ix, b, n_units);
   return hipGetLastError();
 }
 
