@@ -32,6 +32,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def traffic_bytes(args, nq, world):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/traffic.json:
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction of MI355X_MICROARCH.md), when a
+    pass for exactly this workload was committed; else None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return t.get(f"tweets={args.tweets},queries={nq},alg={args.alg},gpus={world},partitions={args.partitions or 32}")
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,11 +119,12 @@ def main():
     # ---- multi-GPU plumbing: one packed buffer per rank -> one all_gather -> exact merge ------
     if world > 1:
         stream = torch.cuda.current_stream().cuda_stream
-        L = 2 * nq * stride + nq  # int64 words: ids | score bits | (counts int32[nq], map sizes int32[nq])
+        L = pkg.sharding.packed_words(nq, stride)  # int64 words: ids | score bits | counts, map sizes (int32)
         mine = torch.zeros(L, dtype=torch.int64, device="cuda")
         gathered = torch.zeros(world * L, dtype=torch.int64, device="cuda")
         base = mine.data_ptr()
-        qb.bind_outputs(base, base + nq * stride * 8, base + 2 * nq * stride * 8, base + 2 * nq * stride * 8 + nq * 4)
+        o_ids, o_sc, o_cnt, o_msz = pkg.sharding.packed_offsets(nq, stride)
+        qb.bind_outputs(base + o_ids, base + o_sc, base + o_cnt, base + o_msz)
         g = gathered.data_ptr()
         out_ids = torch.zeros((nq, stride), dtype=torch.int64, device="cuda")
         out_sc = torch.zeros((nq, stride), dtype=torch.float64, device="cuda")
@@ -124,8 +136,8 @@ def main():
         qb.run(stream)
         if world > 1:
             dist.all_gather_into_tensor(gathered, mine)
-            rc = lib.sann_merge_shards(local_rank, ctypes.c_void_p(stream), world, nq, stride, L * 8, g,
-                                       g + nq * stride * 8, g + 2 * nq * stride * 8, g + 2 * nq * stride * 8 + nq * 4,
+            rc = lib.sann_merge_shards(local_rank, ctypes.c_void_p(stream), world, nq, stride, L * 8, g + o_ids,
+                                       g + o_sc, g + o_cnt, g + o_msz,
                                        d_k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr())
             assert rc == 0, lib.sann_last_error()
         qb.finish(stream)  # waits for the stream; re-runs whatever the fast path flagged
@@ -148,6 +160,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     unit_ms, merge_ms, n_timed = qb.kernel_times()
+    desc_ms = qb.desc_time()
     qb.set_profiling(False)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -208,7 +221,8 @@ def main():
     unit_avg_ms = unit_ms / max(n_timed, 1)
     achieved = alg_bytes / (unit_avg_ms * 1e-3) / 1e9 if unit_avg_ms > 0 else 0.0
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "kernel": "sann unit kernel (gather+accumulate+select)", "kernel_avg_ms": unit_avg_ms,
+            "traffic": traffic_bytes(args, nq, world), "kernel": "sann::unit_fast_kernel (gather+accumulate+select)",
+            "kernel_avg_ms": unit_avg_ms, "desc_kernel_avg_ms": desc_ms / max(n_timed, 1),
             "merge_kernel_avg_ms": merge_ms / max(n_timed, 1), "algorithmic_bytes_per_launch": alg_bytes}
 
     line = {

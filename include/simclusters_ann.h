@@ -188,6 +188,8 @@ int sann_batch_stats(sann_batch_t *batch, sann_batch_stats_t *stats);
  * the elapsed times to running totals.  Resets the totals. */
 int sann_batch_set_profiling(sann_batch_t *batch, int32_t enable);
 int sann_batch_kernel_times(sann_batch_t *batch, double *unit_ms_total, double *merge_ms_total, int32_t *n_runs);
+/* Total of the descriptor kernel (fast path only) over the same runs. */
+int sann_batch_desc_time(sann_batch_t *batch, double *desc_ms_total);
 /* Debug: enable=1 makes the fast unit kernel stamp s_memtime at its phase boundaries into a side
  * buffer; enable=0 returns the averages (avg16[0] = whole unit, avg16[i] = phase i, shader
  * clocks, avg16[15] = units counted) and frees the buffer.  Never quote a run timed this way. */
@@ -196,6 +198,10 @@ int sann_debug_phase_cycles(sann_batch_t *batch, int32_t enable, double *avg16);
  * units overflowed: [1] too many scanned clusters, [2] too many postings, [3] too many
  * multi-cluster tweets, [4] score outside the fp32 pre-filter range / hash clash, [5] tie group. */
 int sann_debug_overflow_reasons(sann_batch_t *batch, int32_t *counts8, int32_t *n_inexact);
+/* The shard (GPU) and the in-shard partition a tweet belongs to.  Pure host functions (no HIP call):
+ * a front end can use them to route or audit, and the CPU tests use them to emulate shards. */
+int32_t sann_tweet_shard(int64_t tweet_id, int32_t n_shards);
+int32_t sann_tweet_partition(int64_t tweet_id, int32_t n_partitions);
 /* hipDeviceSynchronize on `device` (for callers that do not link the HIP runtime themselves). */
 int sann_device_synchronize(int32_t device);
 int sann_batch_destroy(sann_batch_t *batch);

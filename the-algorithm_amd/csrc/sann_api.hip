@@ -84,9 +84,9 @@ struct sann_batch {
   bool ran = false;
   // optional HIP-event timing of the kernels, on the stream they are launched on
   bool profiling = false;
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool ev_pending = false;
-  double unit_ms_total = 0.0, merge_ms_total = 0.0;
+  double desc_ms_total = 0.0, unit_ms_total = 0.0, merge_ms_total = 0.0;
   int timed_runs = 0;
 
   ~sann_batch() {
@@ -542,6 +542,7 @@ int sann_batch_run(sann_batch_t *b, void *hip_stream) {
     if (b->use_fast) {
       hipError_t e = launch_desc(b->ix->view(), b->view(), b->n_units, st);
       if (e != hipSuccess) return fail(SANN_EDEVICE, std::string("launch_desc: ") + hipGetErrorString(e));
+      if (b->profiling) HIP_TRY(hipEventRecord(b->ev[3], st));
       e = launch_unit_fast(b->ix->view(), b->view(), b->fast, b->n_units, st);
       if (e != hipSuccess) return fail(SANN_EDEVICE, std::string("launch_unit_fast: ") + hipGetErrorString(e));
     } else {
@@ -566,9 +567,14 @@ int sann_batch_finish(sann_batch_t *b, void *hip_stream) {
   HIP_TRY(hipStreamSynchronize(st));
   if (b->nq == 0) return SANN_OK;
   if (b->ev_pending) {
-    float a = 0.f, c = 0.f;
+    float a = 0.f, c = 0.f, d = 0.f;
     HIP_TRY(hipEventElapsedTime(&a, b->ev[0], b->ev[1]));
     HIP_TRY(hipEventElapsedTime(&c, b->ev[1], b->ev[2]));
+    if (b->use_fast) {
+      HIP_TRY(hipEventElapsedTime(&d, b->ev[0], b->ev[3]));  // descriptor kernel
+      a -= d;
+    }
+    b->desc_ms_total += d;
     b->unit_ms_total += a;
     b->merge_ms_total += c;
     b->timed_runs++;
@@ -674,7 +680,7 @@ int sann_batch_set_profiling(sann_batch_t *b, int32_t enable) {
     for (auto &e : b->ev)
       if (!e) HIP_TRY(hipEventCreate(&e));
   b->profiling = enable != 0;
-  b->unit_ms_total = b->merge_ms_total = 0.0;
+  b->desc_ms_total = b->unit_ms_total = b->merge_ms_total = 0.0;
   b->timed_runs = 0;
   b->ev_pending = false;
   return SANN_OK;
@@ -682,6 +688,8 @@ int sann_batch_set_profiling(sann_batch_t *b, int32_t enable) {
 
 int sann_batch_kernel_times(sann_batch_t *b, double *unit_ms_total, double *merge_ms_total, int32_t *n_runs) {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  // unit_ms_total covers the unit kernel alone; the descriptor kernel is reported by
+  // sann_batch_desc_time
   if (unit_ms_total) *unit_ms_total = b->unit_ms_total;
   if (merge_ms_total) *merge_ms_total = b->merge_ms_total;
   if (n_runs) *n_runs = b->timed_runs;
@@ -728,6 +736,19 @@ int sann_debug_overflow_reasons(sann_batch_t *b, int32_t *counts8, int32_t *n_in
     if (fl[(size_t)u] & UNIT_OVERFLOW) counts8[std::min<uint64_t>(thr[(size_t)u * 2 + 1], 7)]++;
   if (n_inexact) *n_inexact = b->h_status ? b->h_status[1] : 0;
   return SANN_OK;
+}
+
+int sann_batch_desc_time(sann_batch_t *b, double *desc_ms_total) {
+  if (!b || !desc_ms_total) return fail(SANN_EINVAL, "NULL argument");
+  *desc_ms_total = b->desc_ms_total;
+  return SANN_OK;
+}
+
+int32_t sann_tweet_shard(int64_t tweet_id, int32_t n_shards) {
+  return n_shards <= 1 ? 0 : (int32_t)tweet_shard(mix64((uint64_t)tweet_id), (uint32_t)n_shards);
+}
+int32_t sann_tweet_partition(int64_t tweet_id, int32_t n_partitions) {
+  return n_partitions <= 1 ? 0 : (int32_t)tweet_partition(mix64((uint64_t)tweet_id), (uint32_t)n_partitions);
 }
 
 int sann_device_synchronize(int32_t device) {

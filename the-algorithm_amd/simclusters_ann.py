@@ -152,6 +152,9 @@ _PROTOS = {
     "sann_batch_stats": (C.c_int, [C.c_void_p, C.POINTER(sann_batch_stats_t)]),
     "sann_batch_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "sann_batch_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "sann_batch_desc_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "sann_tweet_shard": (C.c_int32, [C.c_int64, C.c_int32]),
+    "sann_tweet_partition": (C.c_int32, [C.c_int64, C.c_int32]),
     "sann_device_synchronize": (C.c_int, [C.c_int32]),
     "sann_debug_overflow_reasons": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sann_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
@@ -383,6 +386,11 @@ class QueryBatch:
         a, b, n = C.c_double(), C.c_double(), C.c_int32()
         _check(load_library().sann_batch_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
+
+    def desc_time(self) -> float:
+        d = C.c_double()
+        _check(load_library().sann_batch_desc_time(self._h, C.byref(d)))
+        return d.value
 
     def stats(self) -> sann_batch_stats_t:
         s = sann_batch_stats_t()
