@@ -57,6 +57,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-queries", type=int, default=16, help="queries checked bit-for-bit against the oracle")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real multi-GPU path); gloo = host-staged exchange, only to "
+                         "rehearse the N > 1 code path with several ranks sharing one GPU")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cpu_count, 16))")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,8 +76,13 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)  # ranks may share a GPU in a rehearsal
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         os.environ.setdefault("SANN_NO_TORCH", "1")  # torch-free: system HIP runtime, profiler-friendly
 
@@ -135,7 +144,13 @@ def main():
     def step():
         qb.run(stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, mine)
+            if args.backend == "gloo":
+                torch.cuda.current_stream().synchronize()
+                h_all = torch.zeros(world * L, dtype=torch.int64)
+                dist.all_gather_into_tensor(h_all, mine.cpu())
+                gathered.copy_(h_all)
+            else:
+                dist.all_gather_into_tensor(gathered, mine)
             rc = lib.sann_merge_shards(local_rank, ctypes.c_void_p(stream), world, nq, stride, L * 8, g + o_ids,
                                        g + o_sc, g + o_cnt, g + o_msz,
                                        d_k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr())
@@ -149,6 +164,17 @@ def main():
             torch.cuda.synchronize()
         else:
             assert lib.sann_device_synchronize(local_rank) == 0
+
+    def check_sharded_against_unsharded():
+        """Rehearsal only: rank 0 also builds the whole corpus and checks the merged answer."""
+        full = pkg.ClusterTweetIndex.synthetic(args.tweets, pkg.corpus.N_CLUSTERS, seed=pkg.corpus.CORPUS_SEED,
+                                               index_cap=2000, now_ms=now_ms, device=local_rank, n_partitions=args.partitions)
+        qf = pkg.QueryBatch(full, offs, cids, scs, cfg, now_ms=now_ms)
+        qf.run(); qf.finish()
+        f_ids, f_sc, f_cnt, f_msz = qf.results()
+        qf.close(); full.close()
+        return bool(np.array_equal(f_cnt, counts) and np.array_equal(f_msz, msz) and np.array_equal(f_ids, ids)
+                    and np.array_equal(f_sc.view(np.int64), scores.view(np.int64)))
 
     for _ in range(args.warmup):
         step()
@@ -199,8 +225,9 @@ def main():
     # ---- CPU baseline: the C restatement of the Scala path on the host cores, bounded sample ---
     cpu = None
     if not args.no_cpu_baseline and (co is not None or world == 1):
-        cores = os.cpu_count() or 1
-        n_s = min(nq, max(64, 2 * cores))
+        # a 1-GPU box's CPU share is 16 cores even when 256 logical CPUs are visible
+        cores = args.cpu_threads or min(os.cpu_count() or 1, 16)
+        n_s = min(nq, 256)
         L = host_lists(n_s)
         o_i = np.zeros((n_s, 1000), np.int64)
         o_s = np.zeros((n_s, 1000), np.float64)
@@ -249,6 +276,7 @@ def main():
         "recall_at_400_parity": recall_parity,
         "parity_checked_queries": n_check,
         "fallback_units": int(st.n_fallback_units),
+        "sharded_equals_unsharded": check_sharded_against_unsharded() if (world > 1 and args.backend == "gloo") else None,
         "roofline": roof,
         "cpu_baseline": cpu,
         "corpus_build_s": t_corpus,
