@@ -1,0 +1,54 @@
+/*
+ * representation_scorer.h -- C ABI of the batched SimClusters pair scorer (representation-scorer).
+ *
+ * Replaces the `score: (SimClustersEmbedding, SimClustersEmbedding) => Future[Option[Double]]`
+ * member of the pair score stores (all paths relative to /root/reference/):
+ *   src/scala/com/twitter/simclusters_v2/score/SimClustersEmbeddingPairScoreStore.scala:39-199
+ *   bound to algorithm ids by src/thrift/com/twitter/simclusters_v2/score.thrift:14-22 and
+ *   representation-scorer/server/src/main/scala/com/twitter/representationscorer/scorestore/ScoreStore.scala:133-164
+ * and is what ScoreFacadeStore.multiGet's homogeneous-batch fast path
+ * (src/scala/com/twitter/simclusters_v2/score/ScoreFacadeStore.scala:25-51) would call once per batch.
+ * Embedding hydration (`PairScoreStore.multiGet`, score/ScoreStore.scala:56-69) and the
+ * `None`-if-either-side-is-missing rule stay on the JVM side.
+ *
+ * Inputs are embeddings AS THE CLASS HOLDS THEM: `sortedClusterIds` ascending with their
+ * `sortedScores`, all scores > 0, ids unique (the SimClustersEmbedding invariants,
+ * src/scala/com/twitter/simclusters_v2/common/SimClustersEmbedding.scala:28-41).  With
+ * validate != 0 the call checks that on the host and fails with RSX_EINVAL otherwise.
+ */
+#ifndef REPRESENTATION_SCORER_H
+#define REPRESENTATION_SCORER_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSX_OK 0
+#define RSX_EINVAL 1
+#define RSX_EDEVICE 2
+
+/* ScoringAlgorithm, score.thrift:14-22 */
+#define RSX_PAIR_DOT_PRODUCT 1
+#define RSX_PAIR_COSINE 2        /* merge-dot of the PRE-NORMALISED arrays, SimClustersEmbedding.scala:202-208 */
+#define RSX_PAIR_JACCARD 3
+#define RSX_PAIR_EUCLIDEAN 4     /* fold over the union in ascending cluster id (the reference folds a Set) */
+#define RSX_PAIR_MANHATTAN 5
+#define RSX_PAIR_LOG_COSINE 6
+#define RSX_PAIR_EXP_SCALED 7    /* norm = pow(sum x^2, 0.3): device pow, within 2 ulp of libm */
+
+const char *rsx_last_error(void);
+
+/* Host arrays in, host array out (the shape a JNI stub binds).  CSR offsets int64[n_pairs+1]. */
+int rsx_pair_scores(int32_t device, int32_t algorithm, int32_t n_pairs, const int64_t *a_offsets,
+                    const int32_t *a_cluster_ids, const double *a_scores, const int64_t *b_offsets,
+                    const int32_t *b_cluster_ids, const double *b_scores, int32_t validate, double *out_scores);
+
+/* Device pointers in and out, enqueued on `hip_stream`; for callers that keep embeddings resident. */
+int rsx_pair_scores_device(int32_t device, void *hip_stream, int32_t algorithm, int32_t n_pairs, const void *d_a_offsets,
+                           const void *d_a_cluster_ids, const void *d_a_scores, const void *d_b_offsets,
+                           const void *d_b_cluster_ids, const void *d_b_scores, void *d_out_scores);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -18,6 +18,11 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, name), f"{name} declared in include/simclusters_ann.h but not exported"
     # the Python binding covers the whole header too
     assert declared == set(pkg.simclusters_ann.exported_symbols())
+    rsx = open(os.path.join(ROOT, "include", "representation_scorer.h")).read()
+    declared_rsx = set(re.findall(r"\b(rsx_[a-z_0-9]+)\s*\(", rsx))
+    assert declared_rsx == set(pkg.representation_scorer.PROTOS)
+    for name in sorted(declared_rsx):
+        assert hasattr(lib, name), f"{name} declared in include/representation_scorer.h but not exported"
 
 
 def test_version_and_error_paths(pkg):
