@@ -46,9 +46,11 @@
 namespace sann {
 
 constexpr int NSCAN_MAX = 128;   // scanned clusters a fast unit can describe
-constexpr int MCAP = 128;        // postings that may belong to a multi-cluster tweet, per unit
-constexpr int BLOOM_WORDS = 1024;  // 64-bit words of the blocked Bloom filter (64 Kbit, 3 bits per posting)
-constexpr int FBLOOM_WORDS = 256;  // the sparse "flagged" filter
+// Per-unit side tables are sized by the unit's posting capacity (WG*U) so that small units keep
+// LDS small and occupancy high:
+//   blocked Bloom filter  capacity/2 64-bit words (>= 256), 3 bits per posting: ~0.02 % false flags
+//   "flagged" filter      256 words
+//   match list            64 entries up to 1024 postings, 128 above
 constexpr float APPROX_EPS = 4e-6f;  // bound on |approx/exact - 1| of the fp32 pre-filter (actual < 1e-6)
 
 __device__ inline double normalise_f(int alg, double dot, double nsq, double l2norm, double lognorm) {
@@ -141,15 +143,23 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
 }
 __device__ inline uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
 
+constexpr int bloom_log2(int capacity) { return capacity <= 512 ? 8 : capacity <= 1024 ? 9 : 10; }
+
 enum {
   CTL_NFLAG = 0, CTL_NM, CTL_LIVE, CTL_NSURV, CTL_CNT, CTL_SEL_D, CTL_SEL_A, CTL_SEL_B, CTL_BAD, CTL_KMIN, CTL_KMAX,
   CTL_N
 };
 
+// second launch bound = waves per SIMD: small units are asked to fit 8 waves (<= 64 VGPRs); the
+// rare duplicate-resolution code may spill, the common path does not
 template <int WG, int U>
-__global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
+__global__ __launch_bounds__(WG, (U <= 4 ? 8 : 5)) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
   constexpr int SCAP = FAST_SCAP;
-  __shared__ unsigned long long s_bloom[BLOOM_WORDS];
+  constexpr int BW = bloom_log2(WG * U);  // log2 of the Bloom filter's 64-bit words
+  constexpr int BLOOM_ALLOC = 1 << BW;
+  constexpr int FBLOOM_WORDS = 256;
+  constexpr int MCAP = (WG * U <= 1024) ? 64 : 128;
+  __shared__ unsigned long long s_bloom[BLOOM_ALLOC];
   __shared__ uint32_t s_begin[NSCAN_MAX];
   __shared__ uint32_t s_pre[NSCAN_MAX];
   __shared__ uint8_t s_map[WG * U];  // flat posting index -> cluster sequence number
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
 
   // ---- 0. clear ----------------------------------------------------------------------------
   if (tid < CTL_N) s_ctl[tid] = (tid == CTL_KMIN) ? -1 : 0;
-  for (int i = tid; i < BLOOM_WORDS; i += WG) s_bloom[i] = 0ull;
+  for (int i = tid; i < BLOOM_ALLOC; i += WG) s_bloom[i] = 0ull;
   for (int i = tid; i < FBLOOM_WORDS; i += WG) s_fbloom[i] = 0ull;
 
   bool overflow = h.n_scan > NSCAN_MAX;  // uniform
@@ -244,10 +254,10 @@ __global__ __launch_bounds__(WG) void unit_fast_kernel(IndexView ix, BatchView b
         live += __popcll(__ballot(keep));  // wave count, identical in all lanes
         if (keep) {
           // ---- 3a. blocked Bloom filter: three bits of one 64-bit word, one atomic ------------
-          const uint32_t hsh = table_hash(id[u], 28);  // 10 bits word, 3 x 6 bits positions
+          const uint32_t hsh = table_hash(id[u], 28);  // 3 x 6 bits positions, then the word index
           const unsigned long long bits =
               (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63)) | (1ull << ((hsh >> 12) & 63));
-          const unsigned long long old = atomicOr(&s_bloom[hsh >> 18], bits);
+          const unsigned long long old = atomicOr(&s_bloom[hsh >> (28 - BW)], bits);
           if ((old & bits) == bits) {
             // possibly seen before: mark the id's bits in the (sparse) "flagged" filter
             atomicOr(&s_fbloom[hsh >> 20], bits);
