@@ -77,6 +77,8 @@ struct sann_batch {
   DevBuf cand_key2, cand_id2, g_units, g_off, g_slots, g_keys, g_dot, g_nsq, g_queries;
   int g_cap_units = 0;        // units the g_* / cand_*2 buffers can hold
   int64_t g_cap_entries = 0;  // table entries the g_keys/dot/nsq buffers can hold
+  const uint32_t *cut_ptr[4] = {nullptr, nullptr, nullptr, nullptr};  // cached cut tables for up to 4 values of M
+  int32_t cut_M[4] = {-1, -1, -1, -1};
   int32_t *h_status = nullptr;  // pinned: [0] overflow units, [1] inexact queries
   bool use_fast = false;
   FastParams fast{};
@@ -102,6 +104,7 @@ struct sann_batch {
     b.scan_q = scan_q.as<int32_t>();
     b.desc = desc.as<uint32_t>();
     b.unit_T = unit_T.as<int32_t>();
+    for (int j = 0; j < 4; j++) { b.cut[j] = cut_ptr[j]; b.cut_M[j] = cut_M[j]; }
     b.nq = nq;
     b.cap = cap;
     b.cap2 = cap2;
@@ -463,6 +466,35 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
     HIP_TRY(hipMemcpy(b->scan_w.p, b->h_scan_w.data(), b->h_scan_w.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->scan_q.p, b->h_scan_q.data(), b->h_scan_q.size() * 4, hipMemcpyHostToDevice));
   }
+  // cut tables for the batch's (up to 4) distinct values of M, built once per index and M
+  if (b->use_fast) {
+    int n_m = 0;
+    for (int32_t q = 0; q < nq && n_m < 4; q++) {
+      const int32_t M = b->h_hdr[(size_t)q].M;
+      bool seen = false;
+      for (int j = 0; j < n_m; j++) seen = seen || b->cut_M[j] == M;
+      if (seen) continue;
+      const uint32_t *tab = nullptr;
+      {
+        std::lock_guard<std::mutex> lk(ix->cut_mu);
+        for (auto &e : ix->cut_cache)
+          if (e.first == M) tab = e.second->as<uint32_t>();
+        if (!tab && ix->cut_cache.size() < 8) {
+          std::unique_ptr<DevBuf> buf(new DevBuf());
+          HIP_TRY(buf->alloc(std::max<size_t>((size_t)ix->cluster_ids.size() * ix->P, 1) * 4));
+          HIP_TRY(launch_cut(ix->view(), M, buf->as<uint32_t>(), nullptr));
+          HIP_TRY(hipStreamSynchronize(nullptr));
+          tab = buf->as<uint32_t>();
+          ix->cut_cache.emplace_back(M, std::move(buf));
+        }
+      }
+      if (tab) {
+        b->cut_M[n_m] = M;
+        b->cut_ptr[n_m] = tab;
+        n_m++;
+      }
+    }
+  }
   guard.b = nullptr;
   *out = b;
   return SANN_OK;
@@ -701,13 +733,13 @@ int sann_debug_phase_cycles(sann_batch_t *b, int32_t enable, double *avg16) {
   HIP_TRY(hipSetDevice(b->ix->device));
   if (enable) {
     if (!b->prof.p) {
-      HIP_TRY(b->prof.alloc((size_t)std::max(b->n_units, 1) * 16 * 8));
+      HIP_TRY(b->prof.alloc((size_t)(std::max(b->n_units, 1) + std::max(b->nq, 1)) * 16 * 8));
       HIP_TRY(hipMemset(b->prof.p, 0, b->prof.bytes));
     }
     return SANN_OK;
   }
   if (!b->prof.p || !avg16) return fail(SANN_EINVAL, "phase profiling was not enabled");
-  std::vector<unsigned long long> h((size_t)b->n_units * 16);
+  std::vector<unsigned long long> h((size_t)(b->n_units + b->nq) * 16);
   HIP_TRY(hipMemcpy(h.data(), b->prof.p, h.size() * 8, hipMemcpyDeviceToHost));
   for (int i = 0; i < 16; i++) avg16[i] = 0.0;
   int n = 0;
@@ -720,6 +752,18 @@ int sann_debug_phase_cycles(sann_batch_t *b, int32_t enable, double *avg16) {
   }
   for (int i = 0; i < 16; i++) avg16[i] = n ? avg16[i] / n : 0.0;
   avg16[15] = n;
+  // merge kernel stamps (per query) are reported in slots 9..14: phases 1..6
+  {
+    double m[7] = {0, 0, 0, 0, 0, 0, 0};
+    int nm = 0;
+    for (int q = 0; q < b->nq; q++) {
+      const unsigned long long *s = &h[((size_t)b->n_units + q) * 16];
+      if (s[0] == 0 || s[6] == 0) continue;
+      for (int i = 1; i <= 6; i++) m[i] += (double)(s[i] - s[i - 1]);
+      nm++;
+    }
+    for (int i = 1; i <= 6; i++) avg16[8 + i] = nm ? m[i] / nm : 0.0;
+  }
   HIP_TRY(b->prof.alloc(0));
   return SANN_OK;
 }

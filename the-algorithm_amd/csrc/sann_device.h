@@ -61,6 +61,8 @@ struct BatchView {
   const int32_t *scan_q;    // [total_scan] query of every scan entry
   uint32_t *desc;           // [total_scan*P*2] (sub-list start, exclusive prefix of the lengths), unit-major
   int32_t *unit_T;          // [n_units] postings with rank < M the unit scans
+  const uint32_t *cut[4];   // cached cut tables ([n_rows*P], see sann_index::cut_cache) ...
+  int32_t cut_M[4];         // ... for these values of M (-1 = unused slot)
   int32_t nq;
   int32_t cap;              // entries per unit in cand_key/cand_id (fast path)
   int32_t cap2;             // entries per unit in cand_key2/cand_id2 (general path, >= max k)

@@ -74,6 +74,21 @@ __device__ inline int lower_bound_rank(const uint32_t *a, int n, uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Cut table for one value of M: out[row*P + p] = number of postings of sub-list (row, p) with rank < M.
+__global__ __launch_bounds__(256) void cut_kernel(IndexView ix, int M, uint32_t *out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)ix.n_rows * ix.P) return;
+  const uint32_t base = ix.sub_offsets[i], end = ix.sub_offsets[i + 1];
+  const int n = (int)(end - base);
+  out[i] = (n > 0 && ix.ranks[base + n - 1] < (uint32_t)M) ? (uint32_t)n : (uint32_t)lower_bound_rank(ix.ranks + base, n, (uint32_t)M);
+}
+hipError_t launch_cut(const IndexView &ix, int M, uint32_t *out, hipStream_t stream) {
+  const int64_t n = (int64_t)ix.n_rows * ix.P;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cut_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ix, M, out);
+  return hipGetLastError();
+}
+
 // One WAVE per unit: lane c (and c + 64) resolves cluster c's sub-list, the wave scans the lengths,
 // and the unit kernel later reads (start, exclusive prefix) pairs and the unit's posting count.
 __global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, int n_units) {
@@ -89,6 +104,10 @@ __global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, in
     if (lane == 0) b.unit_T[unit] = 0;
     return;
   }
+  const uint32_t *cut = nullptr;  // cached cut table for this query's M, if any (uniform)
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    if (b.cut_M[j] == M) cut = b.cut[j];
   uint32_t base[2], len[2];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
@@ -101,8 +120,10 @@ __global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, in
       const uint32_t end = ix.sub_offsets[(int64_t)row * ix.P + p + 1];
       const int n = (int)(end - base[r]);
       // postings with rank < M are a prefix of the sub-list
-      len[r] = (n > 0 && ix.ranks[base[r] + n - 1] < (uint32_t)M) ? (uint32_t)n
-                                                                 : (uint32_t)lower_bound_rank(ix.ranks + base[r], n, (uint32_t)M);
+      if (cut) len[r] = cut[(int64_t)row * ix.P + p];
+      else
+        len[r] = (n > 0 && ix.ranks[base[r] + n - 1] < (uint32_t)M) ? (uint32_t)n
+                                                                   : (uint32_t)lower_bound_rank(ix.ranks + base[r], n, (uint32_t)M);
     }
   }
   uint32_t incl0 = len[0], incl1 = len[1];

@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/simclusters_ann.h"
@@ -46,6 +49,11 @@ struct sann_index {
   int64_t n_postings = 0, n_postings_total = 0;
   int32_t max_list_len = 0;
   sann_host::DevBuf postings, ranks, sub_offsets;
+  // cut cache: for a given maxTopTweetsPerCluster M, the number of postings with rank < M in every
+  // (row, partition) sub-list.  M is a service-level constant in practice, so this is built once
+  // (one binary search per sub-list, on the device) and reused by every batch.
+  std::mutex cut_mu;
+  std::vector<std::pair<int32_t, std::unique_ptr<sann_host::DevBuf>>> cut_cache;
 
   sann::IndexView view() const {
     sann::IndexView v;

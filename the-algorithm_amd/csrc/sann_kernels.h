@@ -24,6 +24,7 @@ struct FastParams {
   int unit_capacity;  // postings one unit holds in registers (workgroup size x postings per thread)
   int k_local;        // floor on the entries a unit must offer before it may withhold the rest
 };
+hipError_t launch_cut(const IndexView &ix, int M, uint32_t *out, hipStream_t stream);
 hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, hipStream_t stream);
 hipError_t launch_unit_fast(const IndexView &ix, const BatchView &b, const FastParams &fp, int n_units,
                             hipStream_t stream);

@@ -29,7 +29,7 @@ namespace sann {
 
 constexpr int WG = 256;
 constexpr int KMAX = 1024;       // >= MaxNumResultsUpperBound (1000), ApproximateCosineSimilarity.scala:41
-constexpr int MERGE_LDS = 3072;  // entries the merge can stage in LDS
+constexpr int MERGE_LDS = 2048;  // entries the merge stages in LDS per tournament round
 
 // ---------------------------------------------------------------------------------------------
 // normalisation, ApproximateCosineSimilarity.scala:111-119
@@ -319,91 +319,110 @@ __device__ void merge_select_sort_write(const Src &src, int k, int64_t *out_ids,
   if (tid == 0) *out_count = cnt;
 }
 
+__device__ inline uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint64_t o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ inline uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint64_t o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
 // 128-bit radix threshold over LDS arrays: finds thr with  need <= #{key >= thr} <= budget
-// (requires n >= need; keys are unique).  Scores first, from the highest bit in which they
-// differ; if more than `budget` entries tie on the whole score key it continues into the id
-// key, which always separates.  s_ctl: 4 ints, s_mm: 2 u64, s_hist: 256 uints (all LDS).
+// (requires n >= need; keys are unique).  Adaptive: before every digit the min and max of the
+// keys still in play are recomputed and the digit is taken at their highest differing bit, so
+// long common prefixes (the near-tie regime: hundreds of scores equal to the last few ulps) cost
+// nothing.  Scores first; entries that tie on the whole score key are separated by the id key.
+// s_ctl: 4 ints, s_mm: 2 u64, s_hist: 256 uints (all LDS).
 __device__ void lds_radix_cut(const uint64_t *hi, const uint64_t *lo, int n, int need, int budget, unsigned *s_hist,
                               int *s_ctl, uint64_t *s_mm, uint64_t &thr_hi, uint64_t &thr_lo) {
   const int tid = threadIdx.x;
-  uint64_t pre_hi = 0, pre_lo = 0;
-  for (int word = 0; word < 2; word++) {
-    // min / max of the active word among the entries still in play
+  // keys in play: word 0: (hi & mask) == (pre_hi & mask); word 1: hi == pre_hi && (lo & mask) == (pre_lo & mask)
+  uint64_t pre_hi = 0, pre_lo = 0, mask = 0;  // mask = bits already fixed in the active word
+  int word = 0;
+  for (int iter = 0; iter < 40; iter++) {
     uint64_t kmin = ~0ull, kmax = 0ull;
     for (int i = tid; i < n; i += WG) {
-      if (word == 1 && hi[i] != pre_hi) continue;
-      const uint64_t k = word == 0 ? hi[i] : lo[i];
-      kmin = k < kmin ? k : kmin;
-      kmax = k > kmax ? k : kmax;
+      const uint64_t h = hi[i];
+      const bool in = word == 0 ? ((h & mask) == (pre_hi & mask)) : (h == pre_hi && ((lo[i] & mask) == (pre_lo & mask)));
+      const uint64_t k = word == 0 ? h : lo[i];
+      kmin = (in && k < kmin) ? k : kmin;
+      kmax = (in && k > kmax) ? k : kmax;
     }
+    kmin = wave_min_u64(kmin);
+    kmax = wave_max_u64(kmax);
     if (tid == 0) { s_mm[0] = ~0ull; s_mm[1] = 0ull; }
     __syncthreads();
-    atomicMin((unsigned long long *)&s_mm[0], (unsigned long long)kmin);
-    atomicMax((unsigned long long *)&s_mm[1], (unsigned long long)kmax);
+    if ((tid & 63) == 0) {
+      atomicMin((unsigned long long *)&s_mm[0], (unsigned long long)kmin);
+      atomicMax((unsigned long long *)&s_mm[1], (unsigned long long)kmax);
+    }
     __syncthreads();
     const uint64_t gmin = s_mm[0], gmax = s_mm[1];
     const uint64_t diff = gmin ^ gmax;
     __syncthreads();
     if (diff == 0) {
-      // every entry in play has the same value in this word
-      if (word == 0) { pre_hi = gmax; continue; }
+      // everything in play agrees on this whole word
+      if (word == 0) { pre_hi = gmax; word = 1; mask = 0; continue; }
       pre_lo = gmax;
       break;
     }
     const int hbit = 63 - __clzll((long long)diff);
-    int shift = hbit - 7 < 0 ? 0 : hbit - 7;
-    int width = hbit - shift + 1;
-    uint64_t prefix = (hbit == 63) ? 0ull : (gmax >> (hbit + 1)) << (hbit + 1);
-    bool settled = false;
-    for (;;) {
-      for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
-      __syncthreads();
-      const uint64_t hi_mask = (shift + width >= 64) ? 0ull : (~0ull << (shift + width));
-      for (int i = tid; i < n; i += WG) {
-        if (word == 1 && hi[i] != pre_hi) continue;
-        const uint64_t k = word == 0 ? hi[i] : lo[i];
-        if ((k & hi_mask) == (prefix & hi_mask)) atomicAdd(&s_hist[(unsigned)((k >> shift) & ((1u << width) - 1))], 1u);
-      }
-      __syncthreads();
-      if (tid < 64) wave_find_digit(s_hist, need, &s_ctl[1]);
-      __syncthreads();
-      const int d = s_ctl[1], A = s_ctl[2], B = s_ctl[3];
-      prefix |= (uint64_t)d << shift;
-      bool stop = false;
-      if (A + B <= budget) {
-        settled = true;  // everything >= prefix is between need and budget entries
-        stop = true;
-      } else {
-        // digit d alone holds too many: the A entries above it are in, recurse into d
-        need -= A;
-        budget -= A;
-        if (shift == 0) {
-          stop = true;  // they share this whole word: continue in the next word
-        } else {
-          const int ns = shift - 8 < 0 ? 0 : shift - 8;
-          width = shift - ns;
-          shift = ns;
-        }
-      }
-      __syncthreads();
-      if (stop) break;
+    const int shift = hbit - 7 < 0 ? 0 : hbit - 7;
+    const int width = hbit - shift + 1;
+    // all keys in play share the bits above hbit: fix them
+    const uint64_t above = (hbit == 63) ? 0ull : (~0ull << (hbit + 1));
+    if (word == 0) pre_hi = gmax & above; else pre_lo = gmax & above;
+    mask = above;
+    for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += WG) {
+      const uint64_t h = hi[i];
+      const bool in = word == 0 ? ((h & mask) == (pre_hi & mask)) : (h == pre_hi && ((lo[i] & mask) == (pre_lo & mask)));
+      const uint64_t k = word == 0 ? h : lo[i];
+      if (in) atomicAdd(&s_hist[(unsigned)((k >> shift) & ((1u << width) - 1))], 1u);
     }
-    if (word == 0) pre_hi = prefix; else pre_lo = prefix;
-    if (settled) break;
+    __syncthreads();
+    if (tid < 64) wave_find_digit(s_hist, need, &s_ctl[1]);
+    __syncthreads();
+    const int d = s_ctl[1], A = s_ctl[2], B = s_ctl[3];
+    const uint64_t dig = (uint64_t)d << shift;
+    if (word == 0) pre_hi |= dig; else pre_lo |= dig;
+    mask = (shift == 0) ? ~0ull : (~0ull << shift);
+    __syncthreads();
+    if (A + B <= budget) break;  // everything >= the prefix is between need and budget entries
+    // digit d alone holds too many: the A entries above it are in, recurse into d
+    need -= A;
+    budget -= A;
+    if (shift == 0) {
+      // the B entries tie on this whole word
+      if (word == 1) break;  // cannot happen: keys are unique
+      word = 1;
+      mask = 0;
+    }
   }
   thr_hi = pre_hi;
   thr_lo = pre_lo;
 }
 
-// One workgroup per query.  Chunked tournament: the current best (<= KMAX entries, in s_hi2) plus
-// as many unit lists as fit are staged in LDS, cut to the entries that can still be in the
-// top-k, and compacted back; after the last chunk the survivors are sorted.
+// SURV = capacity of the survivor list: 512 when every k of the batch is <= 448 (LDS 40 KB, four
+// workgroups per CU), else 1024.
+template <int SURV>
 __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, const int32_t *query_list) {
   __shared__ uint64_t s_hi[MERGE_LDS], s_lo[MERGE_LDS];
-  __shared__ uint64_t s_hi2[KMAX], s_lo2[KMAX];
+  __shared__ uint64_t s_hi2[SURV], s_lo2[SURV];
   __shared__ uint64_t s_mm[2];
   __shared__ unsigned s_hist[256];
   __shared__ int s_off[WG + 1];
+  __shared__ int s_fb[WG];
   __shared__ int s_ctl[4];
   __shared__ int s_cnt;
 
@@ -413,11 +432,15 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   const int P = ix.P;  // <= 256
   const int64_t unit0 = (int64_t)q * P;
   const int k = h.k;
-  const int budget = k <= 448 ? 512 : KMAX;  // survivors kept between chunks / sorted at the end
+  const int budget = (k <= 448 || SURV < KMAX) ? 512 : KMAX;  // survivors kept between chunks / sorted at the end
+  // debug stamps live after the units' region of the prof buffer
+#define MSTAMP(i) do { if (b.prof && tid == 0) b.prof[((int64_t)b.nq * P + q) * 16 + (i)] = (unsigned long long)clock64(); } while (0)
+  MSTAMP(0);
 
   // offsets of the unit lists in a flat index space (P <= 256: one thread per unit, wave scans)
   {
     int c = tid < P ? b.cand_cnt[unit0 + tid] : 0;
+    s_fb[tid] = tid < P ? b.unit_fb[unit0 + tid] : -1;
     int incl = c;
     const int lane = tid & 63;
 #pragma unroll
@@ -436,11 +459,12 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   int64_t *out_ids = b.out_ids + (int64_t)q * b.stride;
   double *out_scores = b.out_scores + (int64_t)q * b.stride;
 
+  MSTAMP(1);  // offsets
   int best_n = 0;  // entries currently in s_hi2 / s_lo2
   int u_begin = 0;
   while (u_begin < P) {
     // units [u_begin, u_end) such that best + their entries fit (a single list always fits:
-    // MERGE_LDS - KMAX >= any per-unit capacity)
+    // MERGE_LDS - SURV >= any per-unit capacity)
     int u_end = u_begin;
     const int base_off = s_off[u_begin];
     while (u_end < P && best_n + (s_off[u_end + 1] - base_off) <= MERGE_LDS) u_end++;
@@ -455,9 +479,9 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
       for (int u = u_begin + wave; u < u_end; u += WG / 64) {
         const int o = best_n + s_off[u] - base_off, m = s_off[u + 1] - s_off[u];
         if (m > 0) {
-          const uint64_t *key;
-          const int64_t *id;
-          unit_list(b, unit0 + u, key, id);
+          const int fb = s_fb[u];  // preloaded: the list address does not wait on another global load
+          const uint64_t *key = fb < 0 ? b.cand_key + (unit0 + u) * b.cap : b.cand_key2 + (int64_t)fb * b.cap2;
+          const int64_t *id = fb < 0 ? b.cand_id + (unit0 + u) * b.cap : b.cand_id2 + (int64_t)fb * b.cap2;
           for (int j = lane; j < m; j += 64) {
             if (o + j < MERGE_LDS) {
               s_hi[o + j] = key[j];
@@ -468,23 +492,26 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
       }
     }
     __syncthreads();
+    MSTAMP(2);  // staged (last round)
     uint64_t thi = 0, tlo = 0;
     if (n > budget && k > 0) lds_radix_cut(s_hi, s_lo, n, k, budget, s_hist, s_ctl, s_mm, thi, tlo);
+    MSTAMP(3);  // cut found (last round)
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     for (int i = tid; i < n; i += WG) {
       const uint64_t a = s_hi[i], c = s_lo[i];
       if (k > 0 && key_ge(a, c, thi, tlo)) {
         const int o = atomicAdd(&s_cnt, 1);
-        if (o < KMAX) { s_hi2[o] = a; s_lo2[o] = c; }
+        if (o < SURV) { s_hi2[o] = a; s_lo2[o] = c; }
       }
     }
     __syncthreads();
-    best_n = s_cnt < KMAX ? s_cnt : KMAX;
+    best_n = s_cnt < SURV ? s_cnt : SURV;
     u_begin = u_end;
     __syncthreads();
   }
 
+  MSTAMP(4);  // compacted
   // sort the survivors, keep the first k
   uint64_t xk_hi = 0, xk_lo = 0;
   {
@@ -492,6 +519,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
     for (int i = best_n + tid; i < np; i += WG) { s_hi2[i] = 0; s_lo2[i] = 0; }
     __syncthreads();
     bitonic_sort_desc(s_hi2, s_lo2, np);
+    MSTAMP(5);  // sorted
     const int cnt = best_n < k ? best_n : k;
     for (int i = tid; i < cnt; i += WG) {
       out_ids[i] = key_id(s_lo2[i]);
@@ -525,6 +553,8 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
       b.status[2 + o] = q;  // status[2..] = list of inexact queries
     }
   }
+  MSTAMP(6);  // written + proof
+#undef MSTAMP
 }
 
 // Per-shard results (already exact per shard) -> global top-k.  Shard s's arrays start pitch
@@ -599,7 +629,9 @@ hipError_t launch_unit_general(const IndexView &ix, const BatchView &b, const Ge
 hipError_t launch_merge(const IndexView &ix, const BatchView &b, const int32_t *query_list, int n_queries,
                         hipStream_t stream) {
   if (n_queries <= 0) return hipSuccess;
-  hipLaunchKernelGGL(merge_kernel, dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
+  // the 512-entry survivor list serves k <= 448; cap2 is the batch's largest k
+  if (b.cap2 <= 448) hipLaunchKernelGGL(merge_kernel<512>, dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
+  else hipLaunchKernelGGL(merge_kernel<KMAX>, dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
   return hipGetLastError();
 }
 hipError_t launch_merge_shards(int n_shards, int nq, int stride, int64_t pitch, const int64_t *ids, const double *scores,

@@ -27,3 +27,5 @@ names = ["total", "desc+scan", "issue loads", "wait loads+filter+bloom", "dup re
 print("P", P, "units counted", int(avg[15]))
 for i, n in enumerate(names):
     print(f"  {n:28s} {avg[i]:10.0f} clk")
+for i, n in enumerate(["offsets", "stage", "radix cut", "compact", "sort", "write+proof"]):
+    print(f"  merge: {n:21s} {avg[9 + i]:10.0f} clk")
