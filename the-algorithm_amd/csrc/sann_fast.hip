@@ -220,16 +220,20 @@ __global__ __launch_bounds__(WG, (U <= 4 ? 8 : 5)) void unit_fast_kernel(IndexVi
   if (!overflow && T > (uint32_t)(WG * U)) { overflow = true; why = 2; }
   if (!overflow) {
     const uint32_t *d = b.desc + 2 * ((int64_t)h.scan_begin * ix.P + (int64_t)p * h.n_scan);
-    for (int c = tid; c < h.n_scan; c += WG) {
+    // four lanes per cluster: lane part (0..3) fills a quarter of the cluster's stretch of the map
+    for (int t = tid; t < 4 * h.n_scan; t += WG) {
+      const int c = t >> 2, part = t & 3;
       const uint2 v = *reinterpret_cast<const uint2 *>(d + 2 * c);
       const uint32_t next = (c + 1 < h.n_scan) ? d[2 * (c + 1) + 1] : T;
-      const double w = b.scan_w[h.scan_begin + c];
-      s_begin[c] = v.x;
-      s_pre[c] = v.y;
-      s_w[c] = w;
-      s_w32[c] = (float)w;
+      if (part == 0) {
+        const double w = b.scan_w[h.scan_begin + c];
+        s_begin[c] = v.x;
+        s_pre[c] = v.y;
+        s_w[c] = w;
+        s_w32[c] = (float)w;
+      }
       // every posting of this cluster records its cluster in the flat map
-      for (uint32_t i = v.y; i < next; i++) s_map[i] = (uint8_t)c;
+      for (uint32_t i = v.y + part; i < next; i += 4) s_map[i] = (uint8_t)c;
     }
   }
   __syncthreads();
@@ -322,8 +326,9 @@ __global__ __launch_bounds__(WG, (U <= 4 ? 8 : 5)) void unit_fast_kernel(IndexVi
       overflow = true;
       why = 3;
     } else {
-      if (nm > 64) {
-        // large match list (duplicate-heavy corpus): one thread per entry, ids compared inside M
+      if (nm > 64 || nm <= 12) {
+        // tiny match list (a few Bloom false positives: the common case on a large corpus) or a very
+        // large one (duplicate-heavy corpus): one thread per entry, ids compared inside M
         for (int m = tid; m < nm; m += WG) {
           const long long my = s_Mid[m];
           const int myseq = s_Mseq[m];

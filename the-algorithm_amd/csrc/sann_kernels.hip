@@ -138,6 +138,29 @@ __device__ void bitonic_sort_desc(uint64_t *hi, uint64_t *lo, int n) {
   }
 }
 
+// Same sort on packed 16-byte entries {x = score key, y = id key}: one ds_read_b128 / ds_write_b128
+// per element instead of two 8-byte accesses.
+__device__ void bitonic_sort_desc_packed(ulonglong2 *e, int n) {
+  const int tid = threadIdx.x;
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (n >> 1); t += WG) {
+        const int i = 2 * t - (t & (stride - 1));
+        const int j = i + stride;
+        const bool desc = ((i & size) == 0);
+        const ulonglong2 a = e[i], c = e[j];
+        const bool a_lt_c = a.x < c.x || (a.x == c.x && a.y < c.y);
+        const bool a_gt_c = a.x > c.x || (a.x == c.x && a.y > c.y);
+        if (desc ? a_lt_c : a_gt_c) {
+          e[i] = c;
+          e[j] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 __device__ inline int next_pow2(int x) {
   int p = 2;
   while (p < x) p <<= 1;
@@ -418,7 +441,7 @@ __device__ void lds_radix_cut(const uint64_t *hi, const uint64_t *lo, int n, int
 template <int SURV>
 __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, const int32_t *query_list) {
   __shared__ uint64_t s_hi[MERGE_LDS], s_lo[MERGE_LDS];
-  __shared__ uint64_t s_hi2[SURV], s_lo2[SURV];
+  __shared__ ulonglong2 s_e2[SURV];  // survivors, packed {score key, id key}
   __shared__ uint64_t s_mm[2];
   __shared__ unsigned s_hist[256];
   __shared__ int s_off[WG + 1];
@@ -460,7 +483,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   double *out_scores = b.out_scores + (int64_t)q * b.stride;
 
   MSTAMP(1);  // offsets
-  int best_n = 0;  // entries currently in s_hi2 / s_lo2
+  int best_n = 0;  // entries currently in s_e2
   int u_begin = 0;
   while (u_begin < P) {
     // units [u_begin, u_end) such that best + their entries fit (a single list always fits:
@@ -471,24 +494,24 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
     if (u_end == u_begin) u_end = u_begin + 1;  // cannot happen given the capacities; keeps progress
     const int n_new = s_off[u_end] - base_off;
     const int n = best_n + n_new;
-    for (int i = tid; i < best_n; i += WG) { s_hi[i] = s_hi2[i]; s_lo[i] = s_lo2[i]; }
-    {
-      // one wave per unit list: contiguous, coalesced, address-independent loads
-      const int wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < best_n; i += WG) { const ulonglong2 v = s_e2[i]; s_hi[i] = v.x; s_lo[i] = v.y; }
+    // flat over the new entries: every thread finds its list by a search in LDS (offsets and
+    // list pointers were preloaded), so all of a thread's global loads are in flight together
 #pragma unroll 4
-      for (int u = u_begin + wave; u < u_end; u += WG / 64) {
-        const int o = best_n + s_off[u] - base_off, m = s_off[u + 1] - s_off[u];
-        if (m > 0) {
-          const int fb = s_fb[u];  // preloaded: the list address does not wait on another global load
-          const uint64_t *key = fb < 0 ? b.cand_key + (unit0 + u) * b.cap : b.cand_key2 + (int64_t)fb * b.cap2;
-          const int64_t *id = fb < 0 ? b.cand_id + (unit0 + u) * b.cap : b.cand_id2 + (int64_t)fb * b.cap2;
-          for (int j = lane; j < m; j += 64) {
-            if (o + j < MERGE_LDS) {
-              s_hi[o + j] = key[j];
-              s_lo[o + j] = id_key(id[j]);
-            }
-          }
-        }
+    for (int i = tid; i < n_new; i += WG) {
+      const int flat = base_off + i;
+      int u = u_begin;
+      for (int step = 128; step >= 1; step >>= 1) {
+        const int t = u + step;
+        if (t < u_end && s_off[t] <= flat) u = t;
+      }
+      const int fb = s_fb[u];
+      const int j = flat - s_off[u];
+      const uint64_t *key = fb < 0 ? b.cand_key + (unit0 + u) * b.cap : b.cand_key2 + (int64_t)fb * b.cap2;
+      const int64_t *id = fb < 0 ? b.cand_id + (unit0 + u) * b.cap : b.cand_id2 + (int64_t)fb * b.cap2;
+      if (best_n + i < MERGE_LDS) {
+        s_hi[best_n + i] = key[j];
+        s_lo[best_n + i] = id_key(id[j]);
       }
     }
     __syncthreads();
@@ -502,7 +525,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
       const uint64_t a = s_hi[i], c = s_lo[i];
       if (k > 0 && key_ge(a, c, thi, tlo)) {
         const int o = atomicAdd(&s_cnt, 1);
-        if (o < SURV) { s_hi2[o] = a; s_lo2[o] = c; }
+        if (o < SURV) s_e2[o] = make_ulonglong2(a, c);
       }
     }
     __syncthreads();
@@ -516,16 +539,17 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   uint64_t xk_hi = 0, xk_lo = 0;
   {
     const int np = next_pow2(best_n);
-    for (int i = best_n + tid; i < np; i += WG) { s_hi2[i] = 0; s_lo2[i] = 0; }
+    for (int i = best_n + tid; i < np; i += WG) s_e2[i] = make_ulonglong2(0ull, 0ull);
     __syncthreads();
-    bitonic_sort_desc(s_hi2, s_lo2, np);
+    bitonic_sort_desc_packed(s_e2, np);
     MSTAMP(5);  // sorted
     const int cnt = best_n < k ? best_n : k;
     for (int i = tid; i < cnt; i += WG) {
-      out_ids[i] = key_id(s_lo2[i]);
-      out_scores[i] = key_score(s_hi2[i]);
+      const ulonglong2 v = s_e2[i];
+      out_ids[i] = key_id(v.y);
+      out_scores[i] = key_score(v.x);
     }
-    if (cnt == k && cnt > 0) { xk_hi = s_hi2[cnt - 1]; xk_lo = s_lo2[cnt - 1]; }
+    if (cnt == k && cnt > 0) { xk_hi = s_e2[cnt - 1].x; xk_lo = s_e2[cnt - 1].y; }
     if (tid == 0) b.out_counts[q] = cnt;
   }
   __syncthreads();
