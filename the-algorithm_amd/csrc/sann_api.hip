@@ -422,8 +422,8 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
     double est_max = 0.0;
     for (double e : unit_est) est_max = std::max(est_max, e);
     const double need = est_max * 1.25 + 32.0;
-    static const int kCaps[] = {256, 512, 768, 1024, 1536, 2048};  // workgroup size x postings per thread
-    int ucap = 2048;
+    static const int kCaps[] = {256, 512, 768, 1024, 1536, 2048, 3072, 4096};  // workgroup size x postings per thread
+    int ucap = 4096;
     for (int c : kCaps)
       if ((double)c >= need) { ucap = c; break; }
     if (const char *ov = getenv("SANN_UNIT_CAP")) ucap = atoi(ov);  // tuning / test override

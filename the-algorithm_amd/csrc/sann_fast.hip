@@ -164,7 +164,7 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
 }
 __device__ inline uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
 
-constexpr int bloom_log2(int capacity) { return capacity <= 512 ? 8 : capacity <= 1024 ? 9 : 10; }
+constexpr int bloom_log2(int capacity) { return capacity <= 512 ? 8 : capacity <= 1024 ? 9 : capacity <= 2048 ? 10 : 11; }
 
 enum {
   CTL_NFLAG = 0, CTL_NM, CTL_LIVE, CTL_NSURV, CTL_CNT, CTL_SEL_D, CTL_SEL_A, CTL_SEL_B, CTL_BAD, CTL_KMIN, CTL_KMAX,
@@ -174,7 +174,7 @@ enum {
 // second launch bound = waves per SIMD: small units are asked to fit 8 waves (<= 64 VGPRs); the
 // rare duplicate-resolution code may spill, the common path does not
 template <int WG, int U>
-__global__ __launch_bounds__(WG, (U <= 4 ? 8 : 5)) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
+__global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 8 ? 5 : 3)) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
   constexpr int SCAP = FAST_SCAP;
   constexpr int BW = bloom_log2(WG * U);  // log2 of the Bloom filter's 64-bit words
   constexpr int BLOOM_ALLOC = 1 << BW;
@@ -668,6 +668,8 @@ hipError_t launch_unit_fast(const IndexView &ix, const BatchView &b, const FastP
     case 1024: return launch_one<256, 4>(ix, b, fp, stream);
     case 1536: return launch_one<256, 6>(ix, b, fp, stream);
     case 2048: return launch_one<256, 8>(ix, b, fp, stream);
+    case 3072: return launch_one<256, 12>(ix, b, fp, stream);
+    case 4096: return launch_one<256, 16>(ix, b, fp, stream);
     default: return hipErrorInvalidValue;
   }
 }
