@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-queries", type=int, default=16, help="queries checked bit-for-bit against the oracle")
+    ap.add_argument("--quality-queries", type=int, default=8,
+                    help="queries whose result is compared with the exact full-cosine top-400 (device brute force over "
+                         "every tweet's full embedding; N = 1 and --corpus device only; 0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU path); gloo = host-staged exchange, only to "
                          "rehearse the N > 1 code path with several ranks sharing one GPU")
@@ -222,6 +225,19 @@ def main():
             exact += int(ok)
     recall_parity = exact / n_check if n_check else None
 
+    # ---- quality recall@400: approximate top-400 vs the exact full-embedding cosine top-400 --
+    recall_quality = None
+    if world == 1 and co is None and args.quality_queries > 0 and args.alg == "cosine":
+        nqq = min(args.quality_queries, nq)
+        e_ids, _e_cos, e_cnt = index.exact_cosine_topk(offs[:nqq + 1], cids[:offs[nqq]], scs[:offs[nqq]], 400)
+        hit = tot = 0
+        for q in range(nqq):
+            found = set(ids[q, :counts[q]].tolist())
+            truth = e_ids[q, :e_cnt[q]].tolist()[:max(len(found), 1)]  # loadtest definition when shorter than k
+            hit += len(found.intersection(truth))
+            tot += min(len(found), len(truth)) if found else len(truth)
+        recall_quality = hit / max(tot, 1)
+
     # ---- CPU baseline: the C restatement of the Scala path on the host cores, bounded sample ---
     cpu = None
     if not args.no_cpu_baseline and (co is not None or world == 1):
@@ -274,6 +290,8 @@ def main():
         "queries_per_sec": nq * args.steps / elapsed,
         "postings_per_sec": int(st.postings_scanned) * args.steps / elapsed,
         "recall_at_400_parity": recall_parity,
+        "recall_at_400_quality": recall_quality,
+        "quality_checked_queries": (min(args.quality_queries, nq) if recall_quality is not None else 0),
         "parity_checked_queries": n_check,
         "fallback_units": int(st.n_fallback_units),
         "sharded_equals_unsharded": check_sharded_against_unsharded() if (world > 1 and args.backend == "gloo") else None,

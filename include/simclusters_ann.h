@@ -135,6 +135,17 @@ typedef struct sann_synth_params {
   int32_t reserved;
 } sann_synth_params_t;
 int sann_index_build_synthetic(const sann_index_options_t *opts, const sann_synth_params_t *params, sann_index_t **out);
+/* Test / audit hook: the full embeddings the generator gives tweets [t0, t0+n): counts[n] and, at a
+ * fixed stride of 64 entries per tweet, cluster_ids[n*64] and scores[n*64]. */
+int sann_synth_tweet_embeddings(int32_t device, const sann_synth_params_t *params, int64_t t0, int32_t n, int32_t *counts,
+                                int32_t *cluster_ids, double *scores);
+/* Quality truth of SURVEY.md 8(d): for nq (<= 64) source embeddings, the k tweets of the synthetic
+ * corpus with the largest EXACT cosine against their full embeddings (every tweet, every cluster) --
+ * the quantity SimClusters-ANN approximates (simclusters-ann/README.md:18-46).  Brute force on the
+ * device; out arrays are [nq*k], sorted by cosine descending (ties: tweet id ascending). */
+int sann_synth_exact_cosine_topk(int32_t device, const sann_synth_params_t *params, int32_t nq, const int64_t *emb_offsets,
+                                 const int32_t *emb_cluster_ids, const double *emb_scores, int32_t k, int64_t *out_ids,
+                                 double *out_cos, int32_t *out_counts);
 /* Snowflake id the generator gives tweet t (0 <= t < n_tweets). */
 int64_t sann_synth_tweet_id(int64_t t, int64_t n_tweets, int64_t now_ms, int32_t window_hours);
 int sann_index_info(const sann_index_t *index, sann_index_info_t *info);

@@ -93,3 +93,57 @@ def test_queries_on_device_built_index_match_oracle(pkg, oracle, synth):
             assert counts[q] == len(o_ids) and msz[q] == o_msz
             assert np.array_equal(ids[q, :counts[q]], o_ids)
             assert np.array_equal(scores[q, :counts[q]].view(np.int64), o_sc.view(np.int64))
+
+
+def test_tweet_embeddings_agree_with_the_index(pkg):
+    """The full embeddings the quality metric regenerates are the ones the index was built from:
+    every (tweet, cluster, score) whose score reaches the cluster's list is in that list, bit for bit."""
+    n_t, n_c = 40_000, 500
+    ix = pkg.ClusterTweetIndex.synthetic(n_t, n_c, index_cap=2500, n_partitions=4)
+    lib = pkg.load_library()
+    cnt, cl, sc = ix.tweet_embeddings(0, 3000)
+    assert cnt.min() >= 1 and cnt.max() <= 50
+    lists = {}
+    checked = present = 0
+    for i in range(0, 3000, 7):
+        tid = lib.sann_synth_tweet_id(i, n_t, 1_700_000_000_000, 24)
+        assert len(set(cl[i, :cnt[i]].tolist())) == cnt[i], "clusters of a tweet are distinct"
+        for j in range(cnt[i]):
+            c, s = int(cl[i, j]), float(sc[i, j])
+            if c not in lists:
+                t, v, _ = ix.get_list(c)
+                lists[c] = (dict(zip(t.tolist(), v.tolist())), float(v.min()) if len(v) else 0.0, len(v))
+            d, vmin, n = lists[c]
+            checked += 1
+            if tid in d:
+                assert d[tid] == s
+                present += 1
+            else:
+                assert n == 2500 and s <= vmin, "a posting missing from a list must have lost to the cap"
+    assert checked > 1000 and present > 0.5 * checked
+    ix.close()
+
+
+def test_exact_cosine_topk_matches_numpy_brute_force(pkg):
+    n_t, n_c, k = 20_000, 400, 50
+    ix = pkg.ClusterTweetIndex.synthetic(n_t, n_c, index_cap=300, n_partitions=4)
+    lib = pkg.load_library()
+    cnt, cl, sc = ix.tweet_embeddings(0, n_t)
+    offs, cids, scs = pkg.corpus.make_queries(6, n_c, seed=3, clusters_per_user=20)
+    ids, cos, got = ix.exact_cosine_topk(offs, cids, scs, k)
+    tids = np.array([lib.sann_synth_tweet_id(t, n_t, 1_700_000_000_000, 24) for t in range(n_t)], np.int64)
+    mask = np.arange(64)[None, :] < cnt[:, None]
+    tn = np.sqrt((np.where(mask, sc, 0.0) ** 2).sum(1))
+    for q in range(6):
+        w = np.zeros(n_c + 1)
+        w[cids[offs[q]:offs[q + 1]]] = scs[offs[q]:offs[q + 1]]
+        dot = (np.where(mask, sc, 0.0) * w[np.where(mask, cl, 0)]).sum(1)
+        ref = dot / (np.linalg.norm(w) * tn)
+        order = np.lexsort((tids, -ref))[:k]
+        assert got[q] == k
+        # summation order differs from numpy's by an ulp, so near-ties may swap places: compare the
+        # cosines position by position and the id sets away from the k-th boundary
+        assert np.allclose(cos[q], ref[order], rtol=1e-12, atol=0)
+        safe = ref[order] > ref[order][-1] * (1 + 1e-9)
+        assert set(tids[order][safe].tolist()) <= set(ids[q].tolist())
+    ix.close()

@@ -28,6 +28,7 @@
 //   5. scatter_kernel: stable partition of every sorted list into the index layout.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <new>
@@ -109,6 +110,82 @@ __global__ __launch_bounds__(256) void gen_kernel(GenParams g, const float *zthr
       buckets[bucket_off[c] + o] = p;
     } else {
       atomicOr(overflow_flag, 1u);
+    }
+  }
+}
+
+// The full SimClusters embedding of tweet t -- every (cluster, score) the generator draws for it,
+// with the same RNG stream, de-duplication and arithmetic as gen_kernel (which only materialises
+// the postings that can reach a cluster's cap).  Returns the number of entries (<= 64).
+__device__ inline int tweet_embedding(const GenParams &g, int64_t t, int32_t *cl, double *sc) {
+  const uint64_t r0 = rng(g.seed, (uint64_t)t, 0);
+  int n_t = 1 + (int)(__logf((float)u01(r0)) * g.inv_log1mp);
+  if (n_t > g.max_per_tweet) n_t = g.max_per_tweet;
+  if (n_t < 1) n_t = 1;
+  int n = 0;
+  for (int j = 0; j < n_t; j++) {
+    const uint64_t a = rng(g.seed, (uint64_t)t, 1 + 3 * j);
+    int r = (int)exp(u01(a) * g.log_c1);
+    r = r < 1 ? 1 : (r > g.n_clusters ? g.n_clusters : r);
+    const int c = 1 + (int)(((uint64_t)(uint32_t)r * g.perm_mul) % (uint32_t)g.n_clusters);
+    bool dup = false;
+    for (int i = 0; i < n; i++) dup = dup || (cl[i] == c);
+    if (dup || n >= 64) continue;
+    const double u1 = u01(rng(g.seed, (uint64_t)t, 2 + 3 * j)), u2 = u01(rng(g.seed, (uint64_t)t, 3 + 3 * j));
+    const double z = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    double s = exp(-2.0 + z);
+    s = s < 0.001 ? 0.001 : s;
+    cl[n] = c;
+    sc[n] = s;
+    n++;
+  }
+  return n;
+}
+
+// Debug / test export: embeddings of tweets [t0, t0 + n) at a fixed stride of 64 entries.
+__global__ __launch_bounds__(256) void embed_kernel(GenParams g, int64_t t0, int n, int32_t *counts, int32_t *cl, double *sc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int32_t c[64];
+  double s[64];
+  const int m = tweet_embedding(g, t0 + i, c, s);
+  counts[i] = m;
+  for (int j = 0; j < m; j++) { cl[(int64_t)i * 64 + j] = c[j]; sc[(int64_t)i * 64 + j] = s[j]; }
+}
+
+// Exact full-embedding cosine of every tweet against nq source embeddings -- what SANN
+// approximates (simclusters-ann/README.md:18-46); the "quality" recall@k truth of SURVEY 8(d).
+// wtab[q*(C+1) + c] = weight of cluster c in query q (0 when absent), unorm[q] = its l2 norm.
+// mode 0: histogram of the cosines (HB bins over (0,1]); mode 1: emit (tweet, cosine) with
+// cosine >= thr[q].  One thread per tweet.
+constexpr int EXACT_HB = 4096;
+__global__ __launch_bounds__(256) void exact_cosine_kernel(GenParams g, int nq, const double *wtab, const double *unorm,
+                                                           int mode, uint32_t *hist, const double *thr, int64_t *out_ids,
+                                                           double *out_cos, uint32_t *out_cnt, uint32_t out_cap) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= g.n_tweets) return;
+  int32_t c[64];
+  double s[64];
+  const int m = tweet_embedding(g, t, c, s);
+  double tsq = 0.0;
+  for (int j = 0; j < m; j++) tsq += s[j] * s[j];
+  const double tn = sqrt(tsq);
+  for (int q = 0; q < nq; q++) {
+    const double *w = wtab + (int64_t)q * (g.n_clusters + 1);
+    double dot = 0.0;
+    for (int j = 0; j < m; j++) dot += s[j] * w[c[j]];
+    if (!(dot > 0.0)) continue;
+    const double cosv = dot / (unorm[q] * tn);
+    if (mode == 0) {
+      int bin = (int)(cosv * EXACT_HB);
+      bin = bin < 0 ? 0 : (bin >= EXACT_HB ? EXACT_HB - 1 : bin);
+      atomicAdd(&hist[(int64_t)q * EXACT_HB + bin], 1u);
+    } else if (cosv >= thr[q]) {
+      const uint32_t o = atomicAdd(&out_cnt[q], 1u);
+      if (o < out_cap) {
+        out_ids[(int64_t)q * out_cap + o] = synth_tweet_id(t, g.n_tweets, g.ms_begin, g.ms_span);
+        out_cos[(int64_t)q * out_cap + o] = cosv;
+      }
     }
   }
 }
@@ -225,6 +302,28 @@ double inv_norm_cdf(double p) {
 
 uint64_t gcd_u64(uint64_t a, uint64_t b) { return b ? gcd_u64(b, a % b) : a; }
 
+uint32_t perm_multiplier(int C) {
+  uint32_t m = 2654435761u % (uint32_t)C;
+  if (m == 0) m = 1;
+  while (gcd_u64(m, (uint64_t)C) != 1) m++;
+  return m;
+}
+
+GenParams gen_params(const sann_synth_params_t *sp) {
+  GenParams g;
+  const double p_geo = 1.0 / sp->mean_clusters;
+  g.n_tweets = sp->n_tweets;
+  g.n_clusters = sp->n_clusters;
+  g.max_per_tweet = sp->max_clusters_per_tweet;
+  g.inv_log1mp = (float)(1.0 / std::log(1.0 - p_geo));
+  g.log_c1 = std::log((double)sp->n_clusters + 1.0);
+  g.perm_mul = perm_multiplier(sp->n_clusters);
+  g.seed = sp->seed;
+  g.ms_span = (int64_t)sp->window_hours * 3600000ll;
+  g.ms_begin = sp->now_ms - g.ms_span;
+  return g;
+}
+
 }  // namespace
 
 extern "C" {
@@ -250,16 +349,23 @@ int sann_index_build_synthetic(const sann_index_options_t *opts, const sann_synt
   // E[min(max, 1+Geom)] = (1 - (1-p)^max) / p
   const double mean_nt = (1.0 - std::pow(1.0 - p_geo, sp->max_clusters_per_tweet)) / p_geo;
   const double log_c1 = std::log((double)C + 1.0);
-  uint32_t perm_mul = 2654435761u % (uint32_t)C;
-  if (perm_mul == 0) perm_mul = 1;
-  while (gcd_u64(perm_mul, (uint64_t)C) != 1) perm_mul++;
+  const uint32_t perm_mul = perm_multiplier(C);
   std::vector<float> zthr((size_t)C + 1, -1e30f);
   std::vector<uint32_t> boff((size_t)C + 2, 0);
   std::vector<double> expect((size_t)C + 1, 0.0);
   for (int r = 1; r <= C; r++) {
     const int c = 1 + (int)(((uint64_t)(uint32_t)r * perm_mul) % (uint32_t)C);
     const double pr = std::log(1.0 + 1.0 / r) / log_c1;
-    const double L = (double)sp->n_tweets * mean_nt * pr;
+    // expected number of tweets that CONTAIN the cluster (repeated draws inside a tweet are dropped):
+    // P = 1 - E[(1-pr)^n], n = min(N, 1 + Geom(p_geo)); with g = 1 - p_geo, x = 1 - pr:
+    // E[x^n] = p_geo x (1 - (g x)^(N-1)) / (1 - g x) + g^(N-1) x^N.  Counting draws instead would
+    // over-estimate hot clusters (the rank-1 cluster is in ~70 % of all tweets) and cut them short.
+    const double gq = 1.0 - p_geo, xq = 1.0 - pr;
+    const int Nmax = sp->max_clusters_per_tweet;
+    const double exn = p_geo * xq * (1.0 - std::pow(gq * xq, Nmax - 1)) / (1.0 - gq * xq) +
+                       std::pow(gq, Nmax - 1) * std::pow(xq, Nmax);
+    const double L = (double)sp->n_tweets * (1.0 - exn);
+    (void)mean_nt;
     double keep = L;
     if (L > keep_cap) {
       keep = keep_cap;
@@ -304,16 +410,7 @@ int sann_index_build_synthetic(const sann_index_options_t *opts, const sann_synt
   HIP_TRY(hipMemset(d_flag.p, 0, 4));
 
   // ---- 2. generate --------------------------------------------------------------------------------
-  GenParams g;
-  g.n_tweets = sp->n_tweets;
-  g.n_clusters = C;
-  g.max_per_tweet = sp->max_clusters_per_tweet;
-  g.inv_log1mp = (float)(1.0 / std::log(1.0 - p_geo));
-  g.log_c1 = log_c1;
-  g.perm_mul = perm_mul;
-  g.seed = sp->seed;
-  g.ms_span = (int64_t)sp->window_hours * 3600000ll;
-  g.ms_begin = sp->now_ms - g.ms_span;
+  const GenParams g = gen_params(sp);
   const int64_t gen_blocks = (sp->n_tweets + 255) / 256;
   if (gen_blocks > 0x7fffffffll) return fail(SANN_ELIMIT, "too many tweets");
   hipLaunchKernelGGL(gen_kernel, dim3((unsigned)gen_blocks), dim3(256), 0, 0, g, d_zthr.as<float>(), d_boff.as<uint32_t>(),
@@ -380,6 +477,106 @@ int sann_index_build_synthetic(const sann_index_options_t *opts, const sann_synt
   HIP_TRY(hipDeviceSynchronize());
   guard.p = nullptr;
   *out = ix;
+  return SANN_OK;
+}
+
+int sann_synth_tweet_embeddings(int32_t device, const sann_synth_params_t *sp, int64_t t0, int32_t n, int32_t *counts,
+                                int32_t *cluster_ids, double *scores) {
+  if (!sp || n < 0 || t0 < 0 || t0 + n > sp->n_tweets || (n > 0 && (!counts || !cluster_ids || !scores)))
+    return fail(SANN_EINVAL, "bad arguments");
+  if (n == 0) return SANN_OK;
+  HIP_TRY(hipSetDevice(device));
+  DevBuf dc, dl, ds;
+  HIP_TRY(dc.alloc((size_t)n * 4));
+  HIP_TRY(dl.alloc((size_t)n * 64 * 4));
+  HIP_TRY(ds.alloc((size_t)n * 64 * 8));
+  hipLaunchKernelGGL(embed_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, gen_params(sp), t0, n, dc.as<int32_t>(),
+                     dl.as<int32_t>(), ds.as<double>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(counts, dc.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(cluster_ids, dl.p, (size_t)n * 64 * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(scores, ds.p, (size_t)n * 64 * 8, hipMemcpyDeviceToHost));
+  return SANN_OK;
+}
+
+int sann_synth_exact_cosine_topk(int32_t device, const sann_synth_params_t *sp, int32_t nq, const int64_t *emb_offsets,
+                                 const int32_t *emb_cluster_ids, const double *emb_scores, int32_t k, int64_t *out_ids,
+                                 double *out_cos, int32_t *out_counts) {
+  if (!sp || nq < 0 || k < 1 || (nq > 0 && (!emb_offsets || !out_ids || !out_cos || !out_counts)))
+    return fail(SANN_EINVAL, "bad arguments");
+  if (nq == 0) return SANN_OK;
+  if (nq > 64) return fail(SANN_ELIMIT, "at most 64 queries per exact-cosine call");
+  const int C = sp->n_clusters;
+  std::vector<double> wtab((size_t)nq * (C + 1), 0.0), unorm((size_t)nq, 0.0);
+  for (int q = 0; q < nq; q++) {
+    for (int64_t i = emb_offsets[q]; i < emb_offsets[q + 1]; i++) {
+      const int32_t c = emb_cluster_ids[i];
+      if (c < 1 || c > C) return fail(SANN_EINVAL, "query cluster id outside 1..n_clusters");
+      if (emb_scores[i] > 0.0) wtab[(size_t)q * (C + 1) + c] = emb_scores[i];
+    }
+    double ss = 0.0;
+    for (int c = 1; c <= C; c++) ss += wtab[(size_t)q * (C + 1) + c] * wtab[(size_t)q * (C + 1) + c];
+    unorm[(size_t)q] = std::sqrt(ss);
+    if (!(unorm[(size_t)q] > 0.0)) unorm[(size_t)q] = 1.0;
+  }
+  HIP_TRY(hipSetDevice(device));
+  const uint32_t cap = 1u << 16;
+  DevBuf d_w, d_n, d_hist, d_thr, d_ids, d_cos, d_cnt;
+  HIP_TRY(d_w.alloc(wtab.size() * 8));
+  HIP_TRY(d_n.alloc(unorm.size() * 8));
+  HIP_TRY(d_hist.alloc((size_t)nq * EXACT_HB * 4));
+  HIP_TRY(d_thr.alloc((size_t)nq * 8));
+  HIP_TRY(d_ids.alloc((size_t)nq * cap * 8));
+  HIP_TRY(d_cos.alloc((size_t)nq * cap * 8));
+  HIP_TRY(d_cnt.alloc((size_t)nq * 4));
+  HIP_TRY(hipMemcpy(d_w.p, wtab.data(), wtab.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_n.p, unorm.data(), unorm.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d_hist.p, 0, (size_t)nq * EXACT_HB * 4));
+  HIP_TRY(hipMemset(d_cnt.p, 0, (size_t)nq * 4));
+  const GenParams g = gen_params(sp);
+  const unsigned blocks = (unsigned)((sp->n_tweets + 255) / 256);
+  hipLaunchKernelGGL(exact_cosine_kernel, dim3(blocks), dim3(256), 0, 0, g, nq, d_w.as<double>(), d_n.as<double>(), 0,
+                     d_hist.as<uint32_t>(), (const double *)nullptr, (int64_t *)nullptr, (double *)nullptr,
+                     (uint32_t *)nullptr, 0u);
+  HIP_TRY(hipGetLastError());
+  std::vector<uint32_t> hist((size_t)nq * EXACT_HB);
+  HIP_TRY(hipMemcpy(hist.data(), d_hist.p, hist.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<double> thr((size_t)nq, 0.0);
+  for (int q = 0; q < nq; q++) {
+    uint64_t cum = 0;
+    int b = EXACT_HB - 1;
+    for (; b >= 0; b--) {
+      cum += hist[(size_t)q * EXACT_HB + b];
+      if (cum >= (uint64_t)k) break;
+    }
+    thr[(size_t)q] = b <= 0 ? 0.0 : (double)b / EXACT_HB;  // lower edge of the bin that completes the top-k
+    if (cum > cap) return fail(SANN_ELIMIT, "exact cosine: too many candidates share the threshold bin");
+  }
+  HIP_TRY(hipMemcpy(d_thr.p, thr.data(), thr.size() * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(exact_cosine_kernel, dim3(blocks), dim3(256), 0, 0, g, nq, d_w.as<double>(), d_n.as<double>(), 1,
+                     d_hist.as<uint32_t>(), d_thr.as<double>(), d_ids.as<int64_t>(), d_cos.as<double>(),
+                     d_cnt.as<uint32_t>(), cap);
+  HIP_TRY(hipGetLastError());
+  std::vector<uint32_t> cnt((size_t)nq);
+  HIP_TRY(hipMemcpy(cnt.data(), d_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<int64_t> ids(cap);
+  std::vector<double> cs(cap);
+  std::vector<uint32_t> order(cap);
+  for (int q = 0; q < nq; q++) {
+    const uint32_t n = std::min(cnt[(size_t)q], cap);
+    HIP_TRY(hipMemcpy(ids.data(), d_ids.as<int64_t>() + (size_t)q * cap, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cs.data(), d_cos.as<double>() + (size_t)q * cap, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::sort(order.begin(), order.begin() + n, [&](uint32_t a, uint32_t b2) {
+      return cs[a] > cs[b2] || (cs[a] == cs[b2] && ids[a] < ids[b2]);
+    });
+    const int m = (int)std::min<uint32_t>(n, (uint32_t)k);
+    for (int i = 0; i < m; i++) {
+      out_ids[(size_t)q * k + i] = ids[order[(size_t)i]];
+      out_cos[(size_t)q * k + i] = cs[order[(size_t)i]];
+    }
+    out_counts[q] = m;
+  }
   return SANN_OK;
 }
 

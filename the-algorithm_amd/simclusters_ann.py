@@ -139,6 +139,8 @@ _PROTOS = {
     "sann_version": (C.c_char_p, []),
     "sann_index_build": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "sann_index_build_synthetic": (C.c_int, [C.POINTER(sann_index_options_t), C.POINTER(sann_synth_params_t), C.POINTER(C.c_void_p)]),
+    "sann_synth_tweet_embeddings": (C.c_int, [C.c_int32, C.POINTER(sann_synth_params_t), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sann_synth_exact_cosine_topk": (C.c_int, [C.c_int32, C.POINTER(sann_synth_params_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sann_synth_tweet_id": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     "sann_index_info": (C.c_int, [C.c_void_p, C.POINTER(sann_index_info_t)]),
     "sann_index_get_list": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
@@ -248,7 +250,31 @@ class ClusterTweetIndex:
         self.cluster_ids = np.arange(1, n_clusters + 1, dtype=np.int32)
         self.list_offsets = None
         self.now_ms = now_ms
+        self.synth_params = sp
         return self
+
+    def exact_cosine_topk(self, emb_offsets, emb_cluster_ids, emb_scores, k: int):
+        """Quality truth for a synthetic corpus: exact full-embedding cosine top-k (device brute force)."""
+        lib = load_library()
+        eo = np.ascontiguousarray(emb_offsets, np.int64)
+        ec = np.ascontiguousarray(emb_cluster_ids, np.int32)
+        es = np.ascontiguousarray(emb_scores, np.float64)
+        nq = len(eo) - 1
+        ids = np.zeros((nq, k), np.int64)
+        cos = np.zeros((nq, k), np.float64)
+        cnt = np.zeros(nq, np.int32)
+        _check(lib.sann_synth_exact_cosine_topk(self.device, C.byref(self.synth_params), nq, _ptr(eo), _ptr(ec), _ptr(es), k,
+                                                _ptr(ids), _ptr(cos), _ptr(cnt)))
+        return ids, cos, cnt
+
+    def tweet_embeddings(self, t0: int, n: int):
+        """Full embeddings of synthetic tweets [t0, t0+n): (counts[n], cluster_ids[n,64], scores[n,64])."""
+        lib = load_library()
+        cnt = np.zeros(n, np.int32)
+        cl = np.zeros((n, 64), np.int32)
+        sc = np.zeros((n, 64), np.float64)
+        _check(lib.sann_synth_tweet_embeddings(self.device, C.byref(self.synth_params), t0, n, _ptr(cnt), _ptr(cl), _ptr(sc)))
+        return cnt, cl, sc
 
     def export_lists(self, cluster_ids):
         """CSR (cluster_ids, list_offsets, tweet_ids, scores) of the given clusters, copied back from
