@@ -136,3 +136,41 @@ def baseline_run(variant, n_threads, emb_offsets, emb_ids, emb_scores, cfg, now_
     return lib().oracle_baseline_run(int(variant), int(n_threads), nq, _p(emb_offsets), _p(emb_ids), _p(emb_scores),
                                      C.byref(c), int(now_ms), len(cluster_ids), _p(cluster_ids), _p(list_offsets),
                                      _p(tweet_ids), _p(scores), _p(out_ids), _p(out_scores), _p(out_counts))
+
+
+# ---------------------------------------------------------------------------------------------
+# dense exhaustive search.  PARITY UNPINNED: the reference's arithmetic lives in the un-vendored
+# com.twitter.ml.api.embedding.EmbeddingMath (ann/src/main/scala/com/twitter/ann/common/Api.scala:4-12)
+# and the tree holds no test or fixture for it; this restates the published definitions the call
+# sites name (Metric.scala:88-185,263-289; BruteForceIndex.scala:66-91) in float64.
+# ---------------------------------------------------------------------------------------------
+def dense_prepare(metric: int, x: np.ndarray) -> np.ndarray:
+    """What the index stores / the query becomes: Cosine rows are L2-normalised first
+    (DistanceFunctionGenerator.scala:12-30, Hnsw.scala:149-155), then everything is rounded to fp16."""
+    x = np.asarray(x, np.float32)
+    if metric == 1:
+        norm = np.sqrt((x.astype(np.float64) ** 2).sum(axis=1)).astype(np.float32)
+        norm[~(norm > 0)] = 1.0
+        x = x / norm[:, None]
+    return x.astype(np.float16).astype(np.float32)
+
+
+def dense_distances(metric: int, stored: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """Distances of one prepared query to prepared stored vectors (Metric.scala: L2 :88-97,
+    Cosine :119-126 = 1 - cos, InnerProduct :150-158 = 1 - dot), float64."""
+    s, q = stored.astype(np.float64), q.astype(np.float64)
+    if metric == 0:
+        return np.sqrt(((s - q[None, :]) ** 2).sum(axis=1))
+    return 1.0 - s @ q
+
+
+def dense_bruteforce(metric: int, stored: np.ndarray, ids, queries: np.ndarray, k: int):
+    """BruteForceIndex.queryWithDistance (BruteForceIndex.scala:66-91) per prepared query: the k smallest
+    distances ascending; ties (which the reference's heap leaves unspecified) by id ascending."""
+    ids = np.arange(len(stored), dtype=np.int64) if ids is None else np.asarray(ids, np.int64)
+    out = []
+    for q in queries:
+        dist = dense_distances(metric, stored, q)
+        order = np.lexsort((ids, dist))[:k]
+        out.append((ids[order], dist[order]))
+    return out

@@ -23,6 +23,11 @@ def test_library_exports_every_declared_symbol(pkg):
     assert declared_rsx == set(pkg.representation_scorer.PROTOS)
     for name in sorted(declared_rsx):
         assert hasattr(lib, name), f"{name} declared in include/representation_scorer.h but not exported"
+    dann = open(os.path.join(ROOT, "include", "dense_ann.h")).read()
+    declared_dann = set(re.findall(r"\b(dann_[a-z_0-9]+)\s*\(", dann))
+    assert declared_dann == set(pkg.dense_ann.PROTOS)
+    for name in sorted(declared_dann):
+        assert hasattr(lib, name), f"{name} declared in include/dense_ann.h but not exported"
 
 
 def test_version_and_error_paths(pkg):
@@ -36,6 +41,11 @@ def test_version_and_error_paths(pkg):
     assert lib.sann_batch_run(None, None) == 1
     assert lib.sann_batch_destroy(None) == 0
     assert lib.sann_index_destroy(None) == 0
+    dl = pkg.dense_ann._lib()
+    assert dl.dann_index_build(0, 0, 10, 16, None, None, C.byref(h)) == 1  # DANN_EINVAL before any HIP call
+    assert dl.dann_search(None, 1, None, 1, None, None, None) == 1
+    assert b"null" in dl.dann_last_error()
+    assert dl.dann_index_destroy(None) == 0
 
 
 def test_config_struct_layout_matches_header(pkg):

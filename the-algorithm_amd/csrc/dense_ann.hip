@@ -1,0 +1,690 @@
+// dense_ann.hip -- exhaustive dense nearest-neighbour search on the gfx950 matrix cores.
+//
+// What it replaces: BruteForceIndex.queryWithDistance (ann/src/main/scala/com/twitter/ann/brute_force/
+// BruteForceIndex.scala:66-91: score every stored vector, keep the k smallest distances, return them
+// ascending) with the metrics of ann/.../common/Metric.scala:88-185 and the "Cosine = normalise, then
+// InnerProduct" rule of ann/.../hnsw/DistanceFunctionGenerator.scala:12-30.
+//
+// Shape of the computation.  score[v][q] = <x_v, q> (+ a per-vector bias: -|x_v|^2/2 for L2, so that
+// a larger score is always a smaller distance) is a [N x d] * [d x nq] product: with nq ~ 1000
+// queries it has ~1000 flop per index byte, far right of the ridge (2.5 PFLOP/s / 8 TB/s ~ 310), so
+// the path is MFMA-bound and is laid out for v_mfma_f32_32x32x16_f16:
+//   * the index is stored in HBM already in MFMA A-fragment order -- per block of 32 vectors,
+//     [k-step s][lane][8 halves] with lane (r, h) holding x[r][16s + 8h .. +8] -- so a wave loads its
+//     vectors with perfectly coalesced 1-KiB global_load_dwordx4 and keeps them IN REGISTERS
+//     (VB blocks x S k-steps x 4 VGPRs = 128 VGPRs) for the whole life of the workgroup;
+//   * the queries are pre-arranged once per search in the same fragment order (B operand); blocks of
+//     32 queries are streamed through a double-buffered LDS tile shared by the 8 waves, each wave
+//     reading one conflict-free ds_read_b128 per two MFMAs;
+//   * C has the query on the lane and 16 vectors in the accumulator registers, so the per-query
+//     reductions of the epilogue (tile maximum, threshold test) are register-local.
+// The [N x nq] score matrix is never written.  Exact top-k without it:
+//   pass A  the same GEMM over a strided sample of the index writes only per-(query, 64-vector tile)
+//           maxima; tau_q = the k-th largest tile maximum is a lower bound of the k-th best score
+//           (k distinct vectors reach it).  The sample is sized so that ~E_TARGET scores pass tau_q.
+//   pass B  the GEMM over the whole index appends every score >= tau_q to a per-query buffer.
+//   refine  a query whose buffer overflowed takes the k-th largest buffered score as a tighter bound
+//           and pass B is repeated for it (never happens at the sizes pass A is tuned for; it is the
+//           general fallback for tiny indexes / huge k).
+//   select  per query: sort the <= CAP survivors by (score desc, position asc), convert to distances.
+// Positions are in id order (the builder sorts by id), so ties resolve by id ascending.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/dense_ann.h"
+#include "sann_device.h"  // mix64
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &m) {
+  g_err = m;
+  return code;
+}
+#define DTRY(expr)                                                                                \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(DANN_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int WAVES = 8;          // per workgroup: 2 per SIMD, 256 VGPRs each
+constexpr int WG = WAVES * 64;
+constexpr int CAP = 8192;         // survivors kept per query
+constexpr int E_TARGET = 2048;    // survivors pass A aims for
+constexpr int MAX_K = 1024;
+constexpr int MAX_D = 512;
+
+struct Survivor {
+  float score;
+  uint32_t pos;
+};
+
+__device__ __forceinline__ uint32_t f2key(float f) {  // order-preserving float -> uint
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows (fp32, row-major) -> fp16 MFMA fragments.  One wave per row.  Serves the index (A operand)
+// and the queries (B operand): both want "row r of a 32-row block on lane r + 32h, k = 16s + 8h + j".
+// sumsq[row] = sum of the squares of the stored (rounded) halves, in fp32 arithmetic order-fixed.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ void prep_rows_kernel(const float *__restrict__ src, int64_t n, int d, int S, int normalise,
+                                 int64_t row0, _Float16 *__restrict__ frag, float *__restrict__ sumsq) {
+  int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float *x = src + row * d;
+  double ss = 0;
+  for (int k = lane; k < d; k += 64) ss += (double)x[k] * (double)x[k];
+  ss = wave_sum(ss);
+  float norm = 1.0f;
+  if (normalise) {
+    norm = (float)sqrt(ss);
+    if (!(norm > 0.0f)) norm = 1.0f;
+  }
+  int64_t grow = row0 + row;
+  int64_t g = grow >> 5;
+  int r = (int)(grow & 31);
+  double ss16 = 0;
+  for (int k = lane; k < S * 16; k += 64) {
+    float v = k < d ? x[k] / norm : 0.0f;
+    _Float16 hv = (_Float16)v;
+    float back = (float)hv;
+    ss16 += (double)back * (double)back;
+    int s = k >> 4, h = (k >> 3) & 1, j = k & 7;
+    frag[(((g * S + s) * 64) + h * 32 + r) * 8 + j] = hv;
+  }
+  ss16 = wave_sum(ss16);
+  if (lane == 0) sumsq[grow] = (float)ss16;
+}
+
+// bias[v] = 0 (InnerProduct / Cosine), -sumsq/2 (L2), -inf (padding rows)
+__global__ void bias_kernel(float *__restrict__ bias, int64_t n, int64_t n_pad, int metric) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  if (i >= n) bias[i] = -INFINITY;
+  else bias[i] = metric == DANN_METRIC_L2 ? -0.5f * bias[i] : 0.0f;
+}
+
+// fragments -> fp32 rows (audit)
+__global__ void unfrag_kernel(const _Float16 *__restrict__ frag, int S, int d, int64_t i0, int64_t n,
+                              float *__restrict__ out) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * d) return;
+  int64_t row = i0 + e / d;
+  int k = (int)(e % d);
+  int64_t g = row >> 5;
+  int r = (int)(row & 31), s = k >> 4, h = (k >> 3) & 1, j = k & 7;
+  out[e] = (float)frag[(((g * S + s) * 64) + h * 32 + r) * 8 + j];
+}
+
+// synthetic index: i.i.d. N(0,1), one thread per vector
+__device__ __forceinline__ float gauss(uint64_t seed, uint64_t v, uint32_t k) {
+  uint64_t h = sann::mix64(seed ^ (v * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(k >> 1) << 48) ^ (k >> 1));
+  float u1 = ((uint32_t)(h >> 40) + 1u) * (1.0f / 16777217.0f);
+  float u2 = (uint32_t)((h >> 8) & 0xffffffu) * (1.0f / 16777216.0f);
+  float rad = sqrtf(-2.0f * __logf(u1));
+  float ang = 6.2831853f * u2;
+  return (k & 1) ? rad * __sinf(ang) : rad * __cosf(ang);
+}
+
+__global__ void synth_kernel(_Float16 *__restrict__ frag, float *__restrict__ bias, int64_t n, int d, int S,
+                             int metric, uint64_t seed) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  float norm = 1.0f;
+  if (metric == DANN_METRIC_COSINE) {
+    double ss = 0;
+    for (int k = 0; k < d; ++k) {
+      float x = gauss(seed, (uint64_t)v, (uint32_t)k);
+      ss += (double)x * x;
+    }
+    norm = (float)sqrt(ss);
+  }
+  int64_t g = v >> 5;
+  int r = (int)(v & 31);
+  double ss16 = 0;
+  for (int c = 0; c < S * 2; ++c) {  // 8-element chunk c = 2s + h
+    half8 out;
+    for (int j = 0; j < 8; ++j) {
+      int k = c * 8 + j;
+      float x = k < d ? gauss(seed, (uint64_t)v, (uint32_t)k) / norm : 0.0f;
+      _Float16 hv = (_Float16)x;
+      out[j] = hv;
+      ss16 += (double)(float)hv * (double)(float)hv;
+    }
+    *(half8 *)&frag[(((g * S + (c >> 1)) * 64) + (c & 1) * 32 + r) * 8] = out;
+  }
+  bias[v] = (float)ss16;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the GEMM
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+  const _Float16 *xf;    // index fragments
+  const float *bias;     // per vector
+  const _Float16 *qf;    // query fragments
+  int nqb;               // query blocks of 32
+  int64_t n;             // real vectors
+  uint32_t n_wg_total;   // workgroup tiles in the index
+  uint32_t n_wg_launch;  // workgroup tiles this launch covers (sample or all)
+  // pass A
+  float *tmax;           // [nqb*32][pitch]
+  int64_t pitch;
+  // pass B
+  const float *tau;      // [nqb*32]
+  uint32_t *cnt;         // [nqb*32]
+  Survivor *surv;        // [nqb*32][CAP]
+};
+
+template <int S, int VB, bool EMIT>
+__global__ __launch_bounds__(WG) void gemm_kernel(GemmArgs a) {
+  constexpr int CH = S * 64;                  // 16-byte chunks per query block
+  constexpr int NCH = (CH + WG - 1) / WG;
+  __shared__ half8 lds[2][CH];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  // strided sample: launch tile j covers index tile floor(j * total / launch)
+  const uint32_t tile = (uint32_t)(((uint64_t)blockIdx.x * a.n_wg_total) / a.n_wg_launch);
+  const int64_t g0 = ((int64_t)tile * WAVES + w) * VB;  // first 32-vector block of this wave
+
+  half8 av[VB][S];
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+    for (int s = 0; s < S; ++s) av[vb][s] = *(const half8 *)&a.xf[((((g0 + vb) * S + s) * 64) + lane) * 8];
+  // per-vector bias of this wave's rows, re-read (broadcast) at every accumulator reset
+  __shared__ float4 sbias[WAVES][VB][8];
+  if (lane < VB * 8) sbias[w][lane >> 3][lane & 7] = *(const float4 *)&a.bias[g0 * 32 + lane * 4];
+
+  const half8 *qsrc = (const half8 *)a.qf;
+  half8 pre[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (t + c * WG < CH) lds[0][t + c * WG] = qsrc[t + c * WG];
+
+  for (int qb = 0; qb < a.nqb; ++qb) {
+    __syncthreads();
+    const int buf = qb & 1;
+    if (qb + 1 < a.nqb) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (t + c * WG < CH) pre[c] = qsrc[(size_t)(qb + 1) * CH + t + c * WG];
+    }
+    float16v acc[VB];
+#pragma unroll
+    for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {  // register 4*i4 + j is row 8*i4 + 4*(lane >> 5) + j
+        float4 bv = sbias[w][vb][2 * i4 + (lane >> 5)];
+        acc[vb][4 * i4 + 0] = bv.x;
+        acc[vb][4 * i4 + 1] = bv.y;
+        acc[vb][4 * i4 + 2] = bv.z;
+        acc[vb][4 * i4 + 3] = bv.w;
+      }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      half8 b = lds[buf][s * 64 + lane];
+#pragma unroll
+      for (int vb = 0; vb < VB; ++vb) acc[vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[vb][s], b, acc[vb], 0, 0, 0);
+    }
+    if (qb + 1 < a.nqb) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (t + c * WG < CH) lds[buf ^ 1][t + c * WG] = pre[c];
+    }
+    // epilogue: this lane's query is column lane & 31
+    const int q = qb * 32 + (lane & 31);
+    float m = -INFINITY;
+#pragma unroll
+    for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[vb][i]);
+    if (!EMIT) {
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      if (lane < 32) a.tmax[(int64_t)q * a.pitch + (int64_t)blockIdx.x * WAVES + w] = m;
+    } else {
+      const float thr = a.tau[q];
+      if (m >= thr) {
+#pragma unroll
+        for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float sc = acc[vb][i];
+            int64_t v = (g0 + vb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            if (sc >= thr && v < a.n) {
+              uint32_t p = atomicAdd(&a.cnt[q], 1u);
+              if (p < (uint32_t)CAP) a.surv[(size_t)q * CAP + p] = Survivor{sc, (uint32_t)v};
+            }
+          }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-th largest of n floats (stride in floats), one workgroup, 4 radix passes over an LDS histogram
+// ---------------------------------------------------------------------------------------------
+__device__ float wg_kth_largest(const float *vals, int64_t n, int stride, int k, uint32_t *hist /*[258]*/) {
+  uint32_t prefix = 0, mask = 0;
+  uint32_t want = (uint32_t)k;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+      uint32_t key = f2key(vals[i * stride]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t acc = 0;
+      int dgt = 255;
+      for (; dgt > 0; --dgt) {
+        if (acc + hist[dgt] >= want) break;
+        acc += hist[dgt];
+      }
+      hist[256] = (uint32_t)dgt;
+      hist[257] = want - acc;
+    }
+    __syncthreads();
+    prefix |= hist[256] << shift;
+    mask |= 255u << shift;
+    want = hist[257];
+    __syncthreads();
+  }
+  return key2f(prefix);
+}
+
+// tau[q] from the pass-A tile maxima; padded queries get +inf (never emit)
+__global__ void tau_kernel(const float *__restrict__ tmax, int64_t pitch, int64_t n_tiles, int k, int nq,
+                           float *__restrict__ tau, uint32_t *__restrict__ cnt) {
+  __shared__ uint32_t hist[258];
+  int q = blockIdx.x;
+  float v;
+  if (q >= nq) v = INFINITY;
+  else if (n_tiles < k) v = -INFINITY;
+  else v = wg_kth_largest(tmax + (int64_t)q * pitch, n_tiles, 1, k, hist);
+  if (threadIdx.x == 0) {
+    tau[q] = v;
+    cnt[q] = 0;
+  }
+}
+
+// after pass B: overflowed queries get a tighter tau and are re-armed; the others are parked at +inf.
+// status: 0 done, 1 redo, 2 cannot tighten (more than CAP scores tie at the k-th)
+__global__ void refine_kernel(float *__restrict__ tau, uint32_t *__restrict__ cnt, uint32_t *__restrict__ done_cnt,
+                              const Survivor *__restrict__ surv, int k, int nq, int *__restrict__ status,
+                              int *__restrict__ flags) {
+  __shared__ uint32_t hist[258];
+  int q = blockIdx.x;
+  if (q >= nq) return;
+  if (done_cnt[q] != 0xffffffffu) return;  // finished in an earlier round
+  uint32_t c = cnt[q];
+  if (c <= (uint32_t)CAP) {
+    if (threadIdx.x == 0) {
+      done_cnt[q] = c;
+      status[q] = 0;
+      tau[q] = INFINITY;
+    }
+    return;
+  }
+  float old = tau[q];
+  float nt = wg_kth_largest(&surv[(size_t)q * CAP].score, CAP, 2, k, hist);
+  if (threadIdx.x == 0) {
+    if (nt > old) {
+      tau[q] = nt;
+      cnt[q] = 0;
+      status[q] = 1;
+      atomicOr(&flags[0], 1);
+    } else {
+      status[q] = 2;
+      tau[q] = INFINITY;
+      atomicOr(&flags[0], 2);
+    }
+  }
+}
+
+// per query: sort survivors by (score desc, position asc), emit the k nearest as distances
+__global__ __launch_bounds__(512) void select_kernel(const Survivor *__restrict__ surv, const uint32_t *__restrict__ done_cnt,
+                                                     const float *__restrict__ qsumsq, const int64_t *__restrict__ ids,
+                                                     int metric, int k, float *__restrict__ out_dist,
+                                                     int64_t *__restrict__ out_ids, int32_t *__restrict__ out_counts) {
+  extern __shared__ unsigned long long keys[];
+  const int q = blockIdx.x;
+  const uint32_t c = min(done_cnt[q], (uint32_t)CAP);
+  uint32_t n2 = 64;
+  while (n2 < c) n2 <<= 1;
+  for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) {
+    unsigned long long key = 0;
+    if (i < c) {
+      Survivor s = surv[(size_t)q * CAP + i];
+      key = ((unsigned long long)f2key(s.score) << 32) | (0xffffffffu - s.pos);
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  for (uint32_t size = 2; size <= n2; size <<= 1)
+    for (uint32_t str = size >> 1; str > 0; str >>= 1) {
+      for (uint32_t i = threadIdx.x; i < n2 / 2; i += blockDim.x) {
+        uint32_t lo = 2 * i - (i & (str - 1));
+        uint32_t hi = lo + str;
+        bool desc = (lo & size) == 0;
+        unsigned long long x = keys[lo], y = keys[hi];
+        if ((x < y) == desc) {
+          keys[lo] = y;
+          keys[hi] = x;
+        }
+      }
+      __syncthreads();
+    }
+  const uint32_t m = min(c, (uint32_t)k);
+  for (uint32_t i = threadIdx.x; i < (uint32_t)k; i += blockDim.x) {
+    float dist = 0.0f;
+    int64_t id = 0;
+    if (i < m) {
+      unsigned long long key = keys[i];
+      float sc = key2f((uint32_t)(key >> 32));
+      uint32_t pos = 0xffffffffu - (uint32_t)key;
+      id = ids ? ids[pos] : (int64_t)pos;
+      if (metric == DANN_METRIC_L2) dist = sqrtf(fmaxf(0.0f, qsumsq[q] - 2.0f * sc));
+      else dist = 1.0f - sc;
+    }
+    out_dist[(size_t)q * k + i] = dist;
+    out_ids[(size_t)q * k + i] = id;
+  }
+  if (threadIdx.x == 0) out_counts[q] = (int32_t)m;
+}
+
+struct Buf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~Buf() { if (p) (void)hipFree(p); }
+  hipError_t reserve(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+}  // namespace
+
+struct dann_index {
+  int device = 0, metric = 0, d = 0, S = 0, VB = 0;
+  int64_t n = 0, n_pad = 0;
+  Buf xf, bias, ids;
+  bool has_ids = false;
+  // per-search scratch (grown on demand, reused)
+  Buf q_in, qf, qsumsq, tmax, tau, cnt, done_cnt, surv, status, flags, o_dist, o_ids, o_cnt;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float t_a = 0, t_b = 0, t_sel = 0;
+  ~dann_index() {
+    for (auto &e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+};
+
+namespace {
+
+int pick_geometry(int d, int *S, int *VB) {
+  if (d < 1 || d > MAX_D) return fail(DANN_EINVAL, "dimension must be in 1..512");
+  int s = 4;
+  while (s * 16 < d) s <<= 1;
+  *S = s;
+  *VB = s == 32 ? 1 : 2;
+  return DANN_OK;
+}
+
+int alloc_index(dann_index *ix, int device, int metric, int64_t n, int d) {
+  if (metric < DANN_METRIC_L2 || metric > DANN_METRIC_INNER_PRODUCT) return fail(DANN_EINVAL, "unknown metric");
+  if (n < 1 || n >= (int64_t)0xffffff00u) return fail(DANN_EINVAL, "vector count out of range");
+  int rc = pick_geometry(d, &ix->S, &ix->VB);
+  if (rc) return rc;
+  DTRY(hipSetDevice(device));
+  ix->device = device;
+  ix->metric = metric;
+  ix->d = d;
+  ix->n = n;
+  const int64_t tile = (int64_t)WAVES * ix->VB * 32;
+  ix->n_pad = (n + tile - 1) / tile * tile;
+  DTRY(ix->xf.reserve((size_t)ix->n_pad * ix->S * 16 * sizeof(_Float16)));
+  DTRY(ix->bias.reserve((size_t)ix->n_pad * sizeof(float)));
+  DTRY(hipMemset(ix->xf.p, 0, ix->xf.bytes));
+  for (auto &e : ix->ev) DTRY(hipEventCreate(&e));
+  return DANN_OK;
+}
+
+template <int S, int VB>
+void launch_gemm(bool emit, const GemmArgs &a, hipStream_t st) {
+  if (emit) hipLaunchKernelGGL((gemm_kernel<S, VB, true>), dim3(a.n_wg_launch), dim3(WG), 0, st, a);
+  else hipLaunchKernelGGL((gemm_kernel<S, VB, false>), dim3(a.n_wg_launch), dim3(WG), 0, st, a);
+}
+
+void launch_gemm_any(int S, bool emit, const GemmArgs &a, hipStream_t st) {
+  switch (S) {
+    case 4: launch_gemm<4, 2>(emit, a, st); break;
+    case 8: launch_gemm<8, 2>(emit, a, st); break;
+    case 16: launch_gemm<16, 2>(emit, a, st); break;
+    default: launch_gemm<32, 1>(emit, a, st); break;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *dann_last_error(void) { return g_err.c_str(); }
+
+int dann_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                     dann_index_t **out) {
+  if (!vectors || !out) return fail(DANN_EINVAL, "null argument");
+  std::unique_ptr<dann_index> ix(new dann_index);
+  int rc = alloc_index(ix.get(), device, metric, n, d);
+  if (rc) return rc;
+  // positions follow id order, so that "position ascending" is "id ascending" in every tie
+  std::vector<int64_t> order;
+  if (ids) {
+    order.resize((size_t)n);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return ids[x] < ids[y]; });
+    std::vector<int64_t> sorted((size_t)n);
+    for (int64_t i = 0; i < n; ++i) sorted[(size_t)i] = ids[order[(size_t)i]];
+    DTRY(ix->ids.reserve((size_t)n * sizeof(int64_t)));
+    DTRY(hipMemcpy(ix->ids.p, sorted.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+    ix->has_ids = true;
+  }
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(256u << 20) / ((int64_t)d * 4));
+  Buf stage;
+  DTRY(stage.reserve((size_t)std::min(chunk, n) * d * sizeof(float)));
+  std::vector<float> gathered;
+  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+    int64_t m = std::min(chunk, n - r0);
+    const float *src = vectors + r0 * d;
+    if (ids) {
+      gathered.resize((size_t)m * d);
+      for (int64_t i = 0; i < m; ++i)
+        std::memcpy(&gathered[(size_t)i * d], vectors + order[(size_t)(r0 + i)] * d, (size_t)d * sizeof(float));
+      src = gathered.data();
+    }
+    DTRY(hipMemcpy(stage.p, src, (size_t)m * d * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, 0, stage.as<float>(), m, d, ix->S,
+                       metric == DANN_METRIC_COSINE ? 1 : 0, r0, ix->xf.as<_Float16>(), ix->bias.as<float>());
+    DTRY(hipGetLastError());
+    DTRY(hipDeviceSynchronize());
+  }
+  hipLaunchKernelGGL(bias_kernel, dim3((unsigned)((ix->n_pad + 255) / 256)), dim3(256), 0, 0, ix->bias.as<float>(), n,
+                     ix->n_pad, metric);
+  DTRY(hipGetLastError());
+  DTRY(hipDeviceSynchronize());
+  *out = ix.release();
+  return DANN_OK;
+}
+
+int dann_index_build_synthetic(int32_t device, int32_t metric, int64_t n, int32_t d, uint64_t seed, dann_index_t **out) {
+  if (!out) return fail(DANN_EINVAL, "null argument");
+  std::unique_ptr<dann_index> ix(new dann_index);
+  int rc = alloc_index(ix.get(), device, metric, n, d);
+  if (rc) return rc;
+  hipLaunchKernelGGL(synth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ix->xf.as<_Float16>(),
+                     ix->bias.as<float>(), n, d, ix->S, metric, seed);
+  DTRY(hipGetLastError());
+  hipLaunchKernelGGL(bias_kernel, dim3((unsigned)((ix->n_pad + 255) / 256)), dim3(256), 0, 0, ix->bias.as<float>(), n,
+                     ix->n_pad, metric);
+  DTRY(hipGetLastError());
+  DTRY(hipDeviceSynchronize());
+  *out = ix.release();
+  return DANN_OK;
+}
+
+int dann_index_get_vectors(const dann_index_t *ix, int64_t i0, int64_t n, float *out) {
+  if (!ix || !out || i0 < 0 || n < 0 || i0 + n > ix->n) return fail(DANN_EINVAL, "range outside the index");
+  if (n == 0) return DANN_OK;
+  DTRY(hipSetDevice(ix->device));
+  Buf tmp;
+  DTRY(tmp.reserve((size_t)n * ix->d * sizeof(float)));
+  int64_t e = n * ix->d;
+  hipLaunchKernelGGL(unfrag_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, 0, ix->xf.as<_Float16>(), ix->S, ix->d,
+                     i0, n, tmp.as<float>());
+  DTRY(hipGetLastError());
+  DTRY(hipMemcpy(out, tmp.p, (size_t)e * sizeof(float), hipMemcpyDeviceToHost));
+  return DANN_OK;
+}
+
+int dann_index_destroy(dann_index_t *ix) {
+  delete ix;
+  return DANN_OK;
+}
+
+int dann_search(dann_index_t *ix, int32_t nq, const float *queries, int32_t k, float *out_dist, int64_t *out_ids,
+                int32_t *out_counts) {
+  if (!ix || !queries || !out_dist || !out_ids || !out_counts) return fail(DANN_EINVAL, "null argument");
+  if (nq < 1) return fail(DANN_EINVAL, "nq must be positive");
+  if (k < 1 || k > MAX_K) return fail(DANN_EINVAL, "k must be in 1..1024");
+  DTRY(hipSetDevice(ix->device));
+  const int S = ix->S, d = ix->d;
+  const int nqb = (nq + 31) / 32, nq_pad = nqb * 32;
+  const int64_t wg_vecs = (int64_t)WAVES * ix->VB * 32;
+  const uint32_t n_wg = (uint32_t)(ix->n_pad / wg_vecs);
+
+  // pass-A sample: enough workgroup tiles that ~E_TARGET scores clear tau, at least 4k tile maxima
+  uint32_t n_swg = 0;
+  if ((int64_t)n_wg * WAVES >= k) {
+    uint64_t want = ((uint64_t)2 * k * n_wg + E_TARGET - 1) / E_TARGET;
+    uint64_t floor_wg = ((uint64_t)4 * std::max(k, 64) + WAVES - 1) / WAVES;
+    n_swg = (uint32_t)std::min<uint64_t>(n_wg, std::max(want, floor_wg));
+  }
+  const int64_t pitch = (int64_t)n_swg * WAVES;
+
+  DTRY(ix->q_in.reserve((size_t)nq * d * sizeof(float)));
+  DTRY(ix->qf.reserve((size_t)nq_pad * S * 16 * sizeof(_Float16)));
+  DTRY(ix->qsumsq.reserve((size_t)nq_pad * sizeof(float)));
+  DTRY(ix->tmax.reserve((size_t)nq_pad * std::max<int64_t>(pitch, 1) * sizeof(float)));
+  DTRY(ix->tau.reserve((size_t)nq_pad * sizeof(float)));
+  DTRY(ix->cnt.reserve((size_t)nq_pad * sizeof(uint32_t)));
+  DTRY(ix->done_cnt.reserve((size_t)nq_pad * sizeof(uint32_t)));
+  DTRY(ix->status.reserve((size_t)nq_pad * sizeof(int)));
+  DTRY(ix->flags.reserve(sizeof(int)));
+  DTRY(ix->surv.reserve((size_t)nq_pad * CAP * sizeof(Survivor)));
+  DTRY(ix->o_dist.reserve((size_t)nq * k * sizeof(float)));
+  DTRY(ix->o_ids.reserve((size_t)nq * k * sizeof(int64_t)));
+  DTRY(ix->o_cnt.reserve((size_t)nq * sizeof(int32_t)));
+
+  hipStream_t st = 0;
+  DTRY(hipMemcpyAsync(ix->q_in.p, queries, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, st));
+  DTRY(hipMemsetAsync(ix->qf.p, 0, (size_t)nq_pad * S * 16 * sizeof(_Float16), st));
+  DTRY(hipMemsetAsync(ix->status.p, 0, (size_t)nq_pad * sizeof(int), st));
+  DTRY(hipMemsetAsync(ix->done_cnt.p, 0xff, (size_t)nq_pad * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, ix->q_in.as<float>(), (int64_t)nq, d,
+                     S, ix->metric == DANN_METRIC_COSINE ? 1 : 0, (int64_t)0, ix->qf.as<_Float16>(), ix->qsumsq.as<float>());
+  DTRY(hipGetLastError());
+
+  GemmArgs a;
+  a.xf = ix->xf.as<_Float16>();
+  a.bias = ix->bias.as<float>();
+  a.qf = ix->qf.as<_Float16>();
+  a.nqb = nqb;
+  a.n = ix->n;
+  a.n_wg_total = n_wg;
+  a.tmax = ix->tmax.as<float>();
+  a.pitch = pitch;
+  a.tau = ix->tau.as<float>();
+  a.cnt = ix->cnt.as<uint32_t>();
+  a.surv = ix->surv.as<Survivor>();
+
+  DTRY(hipEventRecord(ix->ev[0], st));
+  if (n_swg) {
+    a.n_wg_launch = n_swg;
+    launch_gemm_any(S, false, a, st);
+    DTRY(hipGetLastError());
+  }
+  hipLaunchKernelGGL(tau_kernel, dim3(nq_pad), dim3(256), 0, st, ix->tmax.as<float>(), pitch, pitch, k, nq,
+                     ix->tau.as<float>(), ix->cnt.as<uint32_t>());
+  DTRY(hipGetLastError());
+  DTRY(hipEventRecord(ix->ev[1], st));
+
+  a.n_wg_launch = n_wg;
+  int flags = 0;
+  for (int round = 0;; ++round) {
+    launch_gemm_any(S, true, a, st);
+    DTRY(hipGetLastError());
+    if (round == 0) DTRY(hipEventRecord(ix->ev[2], st));
+    DTRY(hipMemsetAsync(ix->flags.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL(refine_kernel, dim3(nq), dim3(256), 0, st, ix->tau.as<float>(), ix->cnt.as<uint32_t>(),
+                       ix->done_cnt.as<uint32_t>(), ix->surv.as<Survivor>(), k, nq, ix->status.as<int>(), ix->flags.as<int>());
+    DTRY(hipGetLastError());
+    DTRY(hipMemcpyAsync(&flags, ix->flags.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    DTRY(hipStreamSynchronize(st));
+    if (flags & 2) return fail(DANN_ELIMIT, "more than 8192 stored vectors tie at the k-th distance of a query");
+    if (!(flags & 1)) break;
+    if (round >= 16) return fail(DANN_ELIMIT, "threshold refinement did not converge");
+  }
+  DTRY(hipFuncSetAttribute((const void *)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                           CAP * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(512), CAP * sizeof(unsigned long long), st, ix->surv.as<Survivor>(),
+                     ix->done_cnt.as<uint32_t>(), ix->qsumsq.as<float>(), ix->has_ids ? ix->ids.as<int64_t>() : nullptr,
+                     ix->metric, k, ix->o_dist.as<float>(), ix->o_ids.as<int64_t>(), ix->o_cnt.as<int32_t>());
+  DTRY(hipGetLastError());
+  DTRY(hipEventRecord(ix->ev[3], st));
+  DTRY(hipMemcpyAsync(out_dist, ix->o_dist.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+  DTRY(hipMemcpyAsync(out_ids, ix->o_ids.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  DTRY(hipMemcpyAsync(out_counts, ix->o_cnt.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  DTRY(hipStreamSynchronize(st));
+  (void)hipEventElapsedTime(&ix->t_a, ix->ev[0], ix->ev[1]);
+  (void)hipEventElapsedTime(&ix->t_b, ix->ev[1], ix->ev[2]);
+  (void)hipEventElapsedTime(&ix->t_sel, ix->ev[2], ix->ev[3]);
+  return DANN_OK;
+}
+
+int dann_last_timing(const dann_index_t *ix, float *a_ms, float *b_ms, float *sel_ms) {
+  if (!ix) return fail(DANN_EINVAL, "null index");
+  if (a_ms) *a_ms = ix->t_a;
+  if (b_ms) *b_ms = ix->t_b;
+  if (sel_ms) *sel_ms = ix->t_sel;
+  return DANN_OK;
+}
+
+}  // extern "C"
