@@ -122,3 +122,19 @@ def test_argument_errors(pkg):
     with pytest.raises(pkg.dense_ann.DannError):
         pkg.dense_ann.BruteForceIndex.build(m, np.zeros((4, 600), np.float32))
     ix.close()
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(6000, 64, 20, 25), (6000, 16, 1, 5), (40000, 128, 70, 10), (30000, 256, 200, 10)])
+def test_repeated_searches_are_identical_and_exact(pkg, oracle, n, d, nq, k):
+    """Race screen for the LDS-DMA query ring: short k-loops (small d, one or two query blocks) leave
+    the least slack between a stage being issued and being read."""
+    m = pkg.dense_ann.DistanceMetric.InnerProduct
+    rng = np.random.default_rng(n + d)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = pkg.dense_ann.BruteForceIndex.build(m, x)
+    first = _check(pkg, oracle, ix, m, q, k)
+    for _ in range(15):
+        ids, dist, _ = ix.search(q, k)
+        assert np.array_equal(ids, first[0]) and np.array_equal(dist, first[1])
+    ix.close()

@@ -32,11 +32,13 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
 #include <numeric>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/dense_ann.h"
@@ -64,6 +66,7 @@ constexpr int CAP = 8192;         // survivors kept per query
 constexpr int E_TARGET = 2048;    // survivors pass A aims for
 constexpr int MAX_K = 1024;
 constexpr int MAX_D = 512;
+constexpr int MAX_NQ = 4096;     // queries per GEMM launch
 
 struct Survivor {
   float score;
@@ -189,6 +192,8 @@ struct GemmArgs {
   int64_t n;             // real vectors
   uint32_t n_wg_total;   // workgroup tiles in the index
   uint32_t n_wg_launch;  // workgroup tiles this launch covers (sample or all)
+  uint32_t tile0;        // first index tile of this launch
+  uint32_t col0;         // first pass-A column group of this launch
   // pass A
   float *tmax;           // [nqb*32][pitch]
   int64_t pitch;
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(WG) void gemm_kernel(GemmArgs a) {
   __shared__ half8 lds[2][CH];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   // strided sample: launch tile j covers index tile floor(j * total / launch)
-  const uint32_t tile = (uint32_t)(((uint64_t)blockIdx.x * a.n_wg_total) / a.n_wg_launch);
+  const uint32_t tile = a.tile0 + (uint32_t)(((uint64_t)blockIdx.x * a.n_wg_total) / a.n_wg_launch);
   const int64_t g0 = ((int64_t)tile * WAVES + w) * VB;  // first 32-vector block of this wave
 
   half8 av[VB][S];
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(WG) void gemm_kernel(GemmArgs a) {
       for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[vb][i]);
     if (!EMIT) {
       m = fmaxf(m, __shfl_xor(m, 32, 64));
-      if (lane < 32) a.tmax[(int64_t)q * a.pitch + (int64_t)blockIdx.x * WAVES + w] = m;
+      if (lane < 32) a.tmax[(int64_t)q * a.pitch + (int64_t)(a.col0 + blockIdx.x) * WAVES + w] = m;
     } else {
       const float thr = a.tau[q];
       if (m >= thr) {
@@ -280,6 +285,265 @@ __global__ __launch_bounds__(WG) void gemm_kernel(GemmArgs a) {
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM, second geometry: ONE wave per SIMD with the whole 512-register file, registers placed by hand.
+//   * the wave's VB x 32 vectors live in the 256 AGPRs (MFMA reads srcA from AGPRs directly); the
+//     MFMAs are inline asm with an "a" constraint so that the allocator keeps them there -- left to
+//     itself hipcc parks them in AGPRs as spill space and copies each fragment back before use;
+//   * two accumulator sets in VGPRs: while the MFMAs of query block qb fill one, the epilogue of block
+//     qb-1 (maximum, threshold test) runs on the other in the MFMA shadow;
+//   * query fragments come from LDS through a 4-deep register ring that runs straight across block
+//     boundaries (block qb+1 is already readable during block qb, see below), one ds_read_b128 per VB
+//     MFMAs: half the LDS traffic of the 8-wave geometry;
+//   * query blocks arrive by LDS-DMA (global_load_lds_dwordx4 -- the fragment image is lane-linear,
+//     exactly what the DMA writes) into a ring of three slots, two blocks ahead.  The DMA is issued
+//     from inline asm: hipcc otherwise puts s_waitcnt vmcnt(0) in front of every ds_read that
+//     follows a DMA it knows about.  Ordering is by hand: at the top of block qb every wave waits
+//     vmcnt(0) -- retiring stage qb+1, issued a whole block earlier, so the wait is free -- then the
+//     barrier; stage qb+2 is issued after it into the slot block qb-1 was read from.  A slot is
+//     read only after a barrier that followed the wait that retired it.
+// MFMA hazards the compiler cannot see through the asm: see mfma_last_step.
+// ---------------------------------------------------------------------------------------------
+constexpr int W2 = 4;
+constexpr int SB_CAP = 512;  // survivors a workgroup stages in LDS before touching global memory
+struct Staged {
+  float score;
+  uint32_t pos, q;
+};
+
+__device__ __forceinline__ void glds16_asm(const half8 *g, uint32_t lds_byte) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(lds_byte)
+      : "memory");
+}
+
+__device__ __forceinline__ void mfma_first(float16v &d, const half8 &a, const half8 &b) {
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "a"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_bias(float16v &d, const half8 &a, const half8 &b, const float16v &c) {
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void mfma_acc(float16v &d, const half8 &a, const half8 &b) {
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(b));
+}
+
+// The last k-step of a query block: the VB MFMAs and the wait states their results need before any
+// VALU may read them (19 after a 16-pass MFMA), in ONE asm statement.  The compiler cannot see the
+// hazard through the asm and is free to read an accumulator right behind its last MFMA (it does: the
+// register copies at the merge in front of the final epilogue read stale rows 24..31 of the last
+// block); with the wait inside the statement there is no such place.
+template <int VB>
+__device__ __forceinline__ void mfma_last_step(float16v (&c)[VB], const half8 (&a)[VB], const half8 &b) {
+  if constexpr (VB == 4)
+    asm volatile(
+        "v_mfma_f32_32x32x16_f16 %0, %4, %8, %0\n\t"
+        "v_mfma_f32_32x32x16_f16 %1, %5, %8, %1\n\t"
+        "v_mfma_f32_32x32x16_f16 %2, %6, %8, %2\n\t"
+        "v_mfma_f32_32x32x16_f16 %3, %7, %8, %3\n\t"
+        "s_nop 15\n\ts_nop 3"
+        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+        : "a"(a[0]), "a"(a[1]), "a"(a[2]), "a"(a[3]), "v"(b));
+  else
+    asm volatile(
+        "v_mfma_f32_32x32x16_f16 %0, %2, %4, %0\n\t"
+        "v_mfma_f32_32x32x16_f16 %1, %3, %4, %1\n\t"
+        "s_nop 15\n\ts_nop 3"
+        : "+v"(c[0]), "+v"(c[1])
+        : "a"(a[0]), "a"(a[1]), "v"(b));
+}
+
+template <int S, int VB, bool EMIT, bool BIAS>
+__global__ __launch_bounds__(W2 * 64) void gemm2_kernel(GemmArgs a) {
+  constexpr int CH = S * 64, NB = 3, NCH = CH / (W2 * 64);
+  constexpr int FOLD = (VB * 16 + S - 1) / S;  // accumulator registers folded per k-step
+  extern __shared__ half8 smem[];
+  float4 *sbias = (float4 *)(smem + NB * CH);    // [W2][VB][8]
+  uint32_t *sb_n = (uint32_t *)(sbias + W2 * VB * 8);  // survivor staging: count (+ 3 words of padding)
+  Staged *sb = (Staged *)(sb_n + 4);                   // [SB_CAP]
+  float *stau = (float *)(sb + SB_CAP);                // [nqb * 32]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const uint32_t tile = a.tile0 + (uint32_t)(((uint64_t)blockIdx.x * a.n_wg_total) / a.n_wg_launch);
+  const int64_t g0 = ((int64_t)tile * W2 + w) * VB;
+  const half8 *qsrc = (const half8 *)a.qf;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) half8 *)smem;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+
+  auto stage = [&](int qb, int slot) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      glds16_asm(qsrc + (size_t)qb * CH + (c * W2 + wu) * 64 + lane,
+                 lds0 + (uint32_t)((slot * CH + (c * W2 + wu) * 64) * 16));
+  };
+  stage(0, 0);
+  if (a.nqb > 1) stage(1, 1);
+
+  half8 av[VB][S];
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+    for (int s = 0; s < S; ++s) av[vb][s] = *(const half8 *)&a.xf[((((g0 + vb) * S + s) * 64) + lane) * 8];
+  if (BIAS && lane < VB * 8) sbias[w * VB * 8 + lane] = *(const float4 *)&a.bias[g0 * 32 + lane * 4];
+  if (EMIT) {
+    for (int i = t; i < a.nqb * 32; i += W2 * 64) stau[i] = a.tau[i];
+    if (t == 0) *sb_n = 0;
+  }
+  // the compiler does not know about the DMA above: __syncthreads() alone waits for LDS traffic only,
+  // and the fragment ring is primed from slot 0 right behind it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // epilogue of one finished block, split in two: fold() pieces run between the MFMAs of the next
+  // block, finish() after them.
+  float fm[VB];  // running maximum per 32-vector block
+  const uint32_t vbase = (uint32_t)(g0 * 32) + 4u * (uint32_t)(lane >> 5);  // + 32 vb + row(i) = position
+  const uint32_t n32 = (uint32_t)a.n;
+  auto fold = [&](float16v (&p)[VB], int first, int count) {
+#pragma unroll
+    for (int e = first; e < first + count && e < VB * 16; ++e) {
+      const int vb = e >> 4, i = e & 15;
+      float x = p[vb][i];
+      fm[vb] = fmaxf(fm[vb], x);
+    }
+  };
+  auto finish = [&](float16v (&p)[VB], int qb) {
+    const int q = qb * 32 + (lane & 31);
+    if (!EMIT) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float m = VB == 4 ? fmaxf(fm[2 * h], fm[2 * h + 1]) : fm[h];
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (lane < 32) a.tmax[(int64_t)q * a.pitch + ((int64_t)(a.col0 + blockIdx.x) * W2 + w) * 2 + h] = m;
+      }
+    } else {
+      // survivors are rare (about E_TARGET per query over the whole index): test per wave, then per
+      // 32-vector block, and only then per element
+      const float thr = stau[q];
+      float mall = fm[0];
+#pragma unroll
+      for (int vb = 1; vb < VB; ++vb) mall = fmaxf(mall, fm[vb]);
+      if (__builtin_amdgcn_ballot_w64(mall >= thr) != 0) {
+        // opaque copy: keeps the 64 positions (and their bound checks) from being hoisted out of the
+        // block loop into 64 live registers
+        uint32_t vb0 = vbase;
+        asm volatile("" : "+v"(vb0));
+#pragma unroll
+        for (int vb = 0; vb < VB; ++vb) {
+          if (__builtin_amdgcn_ballot_w64(fm[vb] >= thr) == 0) continue;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float sc = p[vb][i];
+            const uint32_t v = vb0 + 32u * vb + (i & 3) + 8 * (i >> 2);
+            // padding rows exist only where the bias path runs (score -inf; they pass only tau = -inf)
+            if (sc >= thr && (!BIAS || v < n32)) {
+              // a returning global atomic costs a round trip to L2 (as long as a whole query block)
+              // and would stall all four waves at the next barrier: stage in LDS, flush at the end
+              uint32_t e = atomicAdd(sb_n, 1u);
+              if (e < (uint32_t)SB_CAP) {
+                sb[e] = Staged{sc, v, (uint32_t)q};
+              } else {
+                uint32_t pos = atomicAdd(&a.cnt[q], 1u);
+                if (pos < (uint32_t)CAP) a.surv[(size_t)q * CAP + pos] = Survivor{sc, v};
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+
+  half8 bq[4];  // fragment ring: k-step s of any block sits in bq[s & 3] (S % 4 == 0)
+#define DANN_LDB(SLOT, STEP) bq[(STEP) & 3] = smem[(SLOT) * CH + (STEP) * 64 + lane]
+
+  // one query block: MFMAs into cur, epilogue of the previous block on prev
+  auto block = [&](auto hp, float16v (&cur)[VB], float16v (&prev)[VB], int qb, int slot) {
+    constexpr bool have_prev = decltype(hp)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int slot2 = slot == 0 ? 2 : slot - 1;  // (qb + 2) % 3
+    const int slot1 = slot == 2 ? 0 : slot + 1;  // (qb + 1) % 3
+    if (qb + 2 < a.nqb) stage(qb + 2, slot2);
+    float16v bt[VB];
+    if (BIAS) {
+#pragma unroll
+      for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          float4 bv = sbias[(w * VB + vb) * 8 + 2 * i4 + (lane >> 5)];
+          bt[vb][4 * i4 + 0] = bv.x;
+          bt[vb][4 * i4 + 1] = bv.y;
+          bt[vb][4 * i4 + 2] = bv.z;
+          bt[vb][4 * i4 + 3] = bv.w;
+        }
+    }
+#pragma unroll
+    for (int vb = 0; vb < VB; ++vb) fm[vb] = -INFINITY;
+    const bool more = qb + 1 < a.nqb;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      // keep the ring 3 fragments ahead; past the end of this block it runs into the next one
+      if (s + 3 < S) DANN_LDB(slot, s + 3);
+      else if (more) DANN_LDB(slot1, s + 3 - S);
+      if (s == S - 1) {
+        half8 al[VB];
+#pragma unroll
+        for (int vb = 0; vb < VB; ++vb) al[vb] = av[vb][S - 1];
+        mfma_last_step<VB>(cur, al, bq[s & 3]);
+      } else {
+#pragma unroll
+        for (int vb = 0; vb < VB; ++vb) {
+          if (s == 0) {
+            if (BIAS) mfma_bias(cur[vb], av[vb][0], bq[0], bt[vb]);
+            else mfma_first(cur[vb], av[vb][0], bq[0]);
+          } else {
+            mfma_acc(cur[vb], av[vb][s], bq[s & 3]);
+          }
+        }
+      }
+      if constexpr (have_prev) fold(prev, s * FOLD, FOLD);
+    }
+    if constexpr (have_prev) finish(prev, qb - 1);
+  };
+
+  float16v acc0[VB], acc1[VB];
+  DANN_LDB(0, 0);
+  DANN_LDB(0, 1);
+  DANN_LDB(0, 2);
+  auto last = [&](float16v (&p)[VB], int qb) {  // epilogue of the final block: nothing left to hide it behind
+#pragma unroll
+    for (int vb = 0; vb < VB; ++vb) fm[vb] = -INFINITY;
+    fold(p, 0, VB * 16);
+    finish(p, qb);
+  };
+  auto next = [](int slot) { return slot == 2 ? 0 : slot + 1; };
+  block(std::false_type{}, acc0, acc1, 0, 0);
+  int slot = 1, qb = 1;
+  for (; qb + 1 < a.nqb; qb += 2) {
+    block(std::true_type{}, acc1, acc0, qb, slot);
+    slot = next(slot);
+    block(std::true_type{}, acc0, acc1, qb + 1, slot);
+    slot = next(slot);
+  }
+  if (qb < a.nqb) {
+    block(std::true_type{}, acc1, acc0, qb, slot);
+    last(acc1, qb);
+  } else {
+    last(acc0, a.nqb - 1);
+  }
+  if (EMIT) {  // flush the staged survivors
+    __syncthreads();
+    const uint32_t ns = min(*sb_n, (uint32_t)SB_CAP);
+    for (uint32_t e = t; e < ns; e += W2 * 64) {
+      const Staged sv = sb[e];
+      uint32_t pos = atomicAdd(&a.cnt[sv.q], 1u);
+      if (pos < (uint32_t)CAP) a.surv[(size_t)sv.q * CAP + pos] = Survivor{sv.score, sv.pos};
+    }
+  }
+#undef DANN_LDB
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -479,17 +743,43 @@ int alloc_index(dann_index *ix, int device, int metric, int64_t n, int d) {
 }
 
 template <int S, int VB>
-void launch_gemm(bool emit, const GemmArgs &a, hipStream_t st) {
+int launch_gemm(bool emit, const GemmArgs &a, hipStream_t st) {
   if (emit) hipLaunchKernelGGL((gemm_kernel<S, VB, true>), dim3(a.n_wg_launch), dim3(WG), 0, st, a);
   else hipLaunchKernelGGL((gemm_kernel<S, VB, false>), dim3(a.n_wg_launch), dim3(WG), 0, st, a);
+  return DANN_OK;
 }
 
-void launch_gemm_any(int S, bool emit, const GemmArgs &a, hipStream_t st) {
+template <int S, int VB>
+int launch_gemm2(bool emit, bool bias, const GemmArgs &a, hipStream_t st) {
+  const size_t lds = (size_t)3 * S * 64 * 16 + (size_t)W2 * VB * 8 * 16 + 16 + (size_t)SB_CAP * sizeof(Staged) +
+                     (size_t)a.nqb * 32 * 4;
+  const void *fn = emit ? (bias ? (const void *)gemm2_kernel<S, VB, true, true> : (const void *)gemm2_kernel<S, VB, true, false>)
+                        : (bias ? (const void *)gemm2_kernel<S, VB, false, true> : (const void *)gemm2_kernel<S, VB, false, false>);
+  DTRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  void *args[] = {(void *)&a};
+  DTRY(hipLaunchKernel(fn, dim3(a.n_wg_launch), dim3(W2 * 64), args, lds, st));
+  return DANN_OK;
+}
+
+// geometry 2 (one wave per SIMD) is the default; DANN_GEOMETRY=1 selects the 8-wave kernel (A/B runs)
+int launch_gemm_any(int S, bool emit, bool bias, const GemmArgs &a, hipStream_t st) {
+  static const int geometry = [] {
+    const char *e = getenv("DANN_GEOMETRY");
+    return e ? atoi(e) : 2;
+  }();
+  if (geometry == 1) {
+    switch (S) {
+      case 4: return launch_gemm<4, 2>(emit, a, st);
+      case 8: return launch_gemm<8, 2>(emit, a, st);
+      case 16: return launch_gemm<16, 2>(emit, a, st);
+      default: return launch_gemm<32, 1>(emit, a, st);
+    }
+  }
   switch (S) {
-    case 4: launch_gemm<4, 2>(emit, a, st); break;
-    case 8: launch_gemm<8, 2>(emit, a, st); break;
-    case 16: launch_gemm<16, 2>(emit, a, st); break;
-    default: launch_gemm<32, 1>(emit, a, st); break;
+    case 4: return launch_gemm2<4, 4>(emit, bias, a, st);
+    case 8: return launch_gemm2<8, 4>(emit, bias, a, st);
+    case 16: return launch_gemm2<16, 4>(emit, bias, a, st);
+    default: return launch_gemm2<32, 2>(emit, bias, a, st);
   }
 }
 
@@ -579,23 +869,52 @@ int dann_index_destroy(dann_index_t *ix) {
   return DANN_OK;
 }
 
+static int search_chunk(dann_index_t *ix, int32_t nq, const float *queries, int32_t k, float *out_dist, int64_t *out_ids,
+                        int32_t *out_counts);
+
 int dann_search(dann_index_t *ix, int32_t nq, const float *queries, int32_t k, float *out_dist, int64_t *out_ids,
                 int32_t *out_counts) {
   if (!ix || !queries || !out_dist || !out_ids || !out_counts) return fail(DANN_EINVAL, "null argument");
   if (nq < 1) return fail(DANN_EINVAL, "nq must be positive");
   if (k < 1 || k > MAX_K) return fail(DANN_EINVAL, "k must be in 1..1024");
+  float ta = 0, tb = 0, ts = 0;
+  for (int32_t q0 = 0; q0 < nq; q0 += MAX_NQ) {  // the GEMM keeps one threshold per query in LDS
+    int32_t m = std::min<int32_t>(MAX_NQ, nq - q0);
+    int rc = search_chunk(ix, m, queries + (size_t)q0 * ix->d, k, out_dist + (size_t)q0 * k, out_ids + (size_t)q0 * k,
+                          out_counts + q0);
+    if (rc) return rc;
+    ta += ix->t_a;
+    tb += ix->t_b;
+    ts += ix->t_sel;
+  }
+  ix->t_a = ta;
+  ix->t_b = tb;
+  ix->t_sel = ts;
+  return DANN_OK;
+}
+
+static int search_chunk(dann_index_t *ix, int32_t nq, const float *queries, int32_t k, float *out_dist, int64_t *out_ids,
+                        int32_t *out_counts) {
   DTRY(hipSetDevice(ix->device));
   const int S = ix->S, d = ix->d;
   const int nqb = (nq + 31) / 32, nq_pad = nqb * 32;
   const int64_t wg_vecs = (int64_t)WAVES * ix->VB * 32;
   const uint32_t n_wg = (uint32_t)(ix->n_pad / wg_vecs);
 
-  // pass-A sample: enough workgroup tiles that ~E_TARGET scores clear tau, at least 4k tile maxima
+  // tiles without padding rows run without the per-vector bias for InnerProduct / Cosine (the
+  // accumulators start at the inline constant 0); the last, partial tile always takes the bias
+  // path, whose -inf keeps the padding rows out of everything.
+  const bool l2 = ix->metric == DANN_METRIC_L2;
+  const uint32_t n_full = (uint32_t)(ix->n / wg_vecs);
+  const bool tail = n_wg > n_full;
+  // pass-A sample (full tiles only): enough workgroup tiles that ~E_TARGET scores clear tau, at
+  // least 4k tile maxima
   uint32_t n_swg = 0;
-  if ((int64_t)n_wg * WAVES >= k) {
+  static const bool no_sample = getenv("DANN_NO_SAMPLE") != nullptr;  // debugging: force the refinement path
+  if ((int64_t)n_full * WAVES >= k && !no_sample) {
     uint64_t want = ((uint64_t)2 * k * n_wg + E_TARGET - 1) / E_TARGET;
     uint64_t floor_wg = ((uint64_t)4 * std::max(k, 64) + WAVES - 1) / WAVES;
-    n_swg = (uint32_t)std::min<uint64_t>(n_wg, std::max(want, floor_wg));
+    n_swg = (uint32_t)std::min<uint64_t>(n_full, std::max(want, floor_wg));
   }
   const int64_t pitch = (int64_t)n_swg * WAVES;
 
@@ -628,7 +947,9 @@ int dann_search(dann_index_t *ix, int32_t nq, const float *queries, int32_t k, f
   a.qf = ix->qf.as<_Float16>();
   a.nqb = nqb;
   a.n = ix->n;
-  a.n_wg_total = n_wg;
+  a.n_wg_total = n_full;
+  a.tile0 = 0;
+  a.col0 = 0;
   a.tmax = ix->tmax.as<float>();
   a.pitch = pitch;
   a.tau = ix->tau.as<float>();
@@ -638,7 +959,8 @@ int dann_search(dann_index_t *ix, int32_t nq, const float *queries, int32_t k, f
   DTRY(hipEventRecord(ix->ev[0], st));
   if (n_swg) {
     a.n_wg_launch = n_swg;
-    launch_gemm_any(S, false, a, st);
+    int rc = launch_gemm_any(S, false, l2, a, st);
+    if (rc) return rc;
     DTRY(hipGetLastError());
   }
   hipLaunchKernelGGL(tau_kernel, dim3(nq_pad), dim3(256), 0, st, ix->tmax.as<float>(), pitch, pitch, k, nq,
@@ -646,11 +968,22 @@ int dann_search(dann_index_t *ix, int32_t nq, const float *queries, int32_t k, f
   DTRY(hipGetLastError());
   DTRY(hipEventRecord(ix->ev[1], st));
 
-  a.n_wg_launch = n_wg;
   int flags = 0;
   for (int round = 0;; ++round) {
-    launch_gemm_any(S, true, a, st);
-    DTRY(hipGetLastError());
+    if (n_full) {
+      a.n_wg_total = a.n_wg_launch = n_full;
+      a.tile0 = 0;
+      int rc = launch_gemm_any(S, true, l2, a, st);
+      if (rc) return rc;
+      DTRY(hipGetLastError());
+    }
+    if (tail) {
+      a.n_wg_total = a.n_wg_launch = 1;
+      a.tile0 = n_full;
+      int rc = launch_gemm_any(S, true, true, a, st);
+      if (rc) return rc;
+      DTRY(hipGetLastError());
+    }
     if (round == 0) DTRY(hipEventRecord(ix->ev[2], st));
     DTRY(hipMemsetAsync(ix->flags.p, 0, sizeof(int), st));
     hipLaunchKernelGGL(refine_kernel, dim3(nq), dim3(256), 0, st, ix->tau.as<float>(), ix->cnt.as<uint32_t>(),
