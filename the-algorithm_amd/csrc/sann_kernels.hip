@@ -10,11 +10,12 @@
 //                        Always correct for any size / duplication; it is the fallback of the
 //                        LDS fast path (sann_fast.hip) and the first path that was parity-green.
 //   merge_kernel         one workgroup per query: exact top-k over the units' candidates under
-//                        the total order (score desc by Double.compare, tweet id asc).  Small
-//                        inputs (<= 4096 entries, the normal case) are bitonic-sorted in LDS;
-//                        larger ones go through an MSB radix select first.  Also proves the
-//                        result exact: a unit that withheld candidates below its threshold is
-//                        harmless iff that threshold is <= the global k-th key.
+//                        the total order (score desc by Double.compare, tweet id asc).  The units'
+//                        lists are streamed through LDS in chunks (a tournament: each chunk is cut
+//                        against the running survivors by an adaptive 128-bit radix select), the
+//                        <= 512 / 1024 survivors are bitonic-sorted as packed 128-bit keys.  Also
+//                        proves the result exact: a unit that withheld candidates below its
+//                        threshold is harmless iff that threshold is <= the global k-th key.
 //   merge_shards_kernel  the same merge over all-gathered per-shard results.
 //
 // Compiled with -ffp-contract=off (see sann_math.h).
