@@ -48,6 +48,40 @@ int rsx_pair_scores_device(int32_t device, void *hip_stream, int32_t algorithm, 
                            const void *d_a_cluster_ids, const void *d_a_scores, const void *d_b_offsets,
                            const void *d_b_cluster_ids, const void *d_b_scores, void *d_out_scores);
 
+/* ---- resident embedding stores: hydration by id on the library side ----
+ * A store is the device-resident counterpart of one `ReadableStore[SimClustersEmbeddingId, SimClustersEmbedding]`
+ * (one (embeddingType, modelVersion)); ids strictly ascending, embeddings in the class's form. */
+typedef struct rsx_store rsx_store_t;
+int rsx_store_build(int32_t device, int64_t n, const int64_t *ids, const int64_t *offsets, const int32_t *cluster_ids,
+                    const double *scores, rsx_store_t **out);
+int rsx_store_destroy(rsx_store_t *store);
+
+/* PairScoreStore.multiGet (src/scala/com/twitter/simclusters_v2/score/ScoreStore.scala:41-69): hydrate both
+ * sides, score; out_present[i] = 0 (None) when either id is not in its store. */
+int rsx_store_pair_scores(const rsx_store_t *a, const rsx_store_t *b, int32_t algorithm, int32_t n_pairs,
+                          const int64_t *a_ids, const int64_t *b_ids, double *out_scores, uint8_t *out_present);
+
+/* ListScoreColumn.fetch (representation-scorer/server/src/main/scala/com/twitter/representationscorer/columns/
+ * ListScoreColumn.scala:53-115): one target against a list of candidates, answers in candidate order,
+ * None for a candidate (or a target) without an embedding. */
+int rsx_store_list_scores(const rsx_store_t *targets, const rsx_store_t *candidates, int32_t algorithm, int64_t target_id,
+                          int32_t n_candidates, const int64_t *candidate_ids, double *out_scores, uint8_t *out_present);
+
+/* Scorer.computeSimilarityScoresPerTweet (representation-scorer/.../twistlyfeatures/Scorer.scala:157-369) with
+ * Scorer.avg / Scorer.max (:426-429), for n_candidates tweets at once.
+ *   maps:   map m = the ids that were scored against every candidate through store map_stores[m]
+ *           (`engagements.tweetIds` / `authorIds`, Engagements.scala:28-33; duplicates are kept and count),
+ *           map_ids[map_id_offsets[m] .. map_id_offsets[m+1]).
+ *   groups: group g = an ordered signal list (favs7d, favs1d, ...) looked up in map group_map[g];
+ *           members group_member_ids[group_offsets[g] .. group_offsets[g+1]).
+ * out_*[c * n_groups + g]: count = number of scores folded (0 => both features are None), avg = left-fold
+ * sum / count, max = fold of max from 0.0.  Pair orientation: score(map embedding, candidate embedding). */
+int rsx_store_group_features(const rsx_store_t *candidates, int32_t algorithm, int32_t n_candidates,
+                             const int64_t *candidate_ids, int32_t n_maps, const rsx_store_t *const *map_stores,
+                             const int64_t *map_id_offsets, const int64_t *map_ids, int32_t n_groups,
+                             const int32_t *group_map, const int64_t *group_offsets, const int64_t *group_member_ids,
+                             double *out_avg, double *out_max, int32_t *out_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,3 +174,46 @@ def dense_bruteforce(metric: int, stored: np.ndarray, ids, queries: np.ndarray, 
         order = np.lexsort((ids, dist))[:k]
         out.append((ids[order], dist[order]))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# representation-scorer list / aggregate columns, restated literally (test infrastructure)
+# ---------------------------------------------------------------------------------------------
+def rsx_list_scores(algorithm, target, candidates):
+    """ListScoreColumn.fetch (representation-scorer/.../columns/ListScoreColumn.scala:53-115): `target` and
+    each candidate are (ids, scores) embeddings or None (not hydrated) -> Option[Double] per candidate."""
+    out = []
+    for c in candidates:
+        out.append(None if target is None or c is None else pair_score(algorithm, target[0], target[1], c[0], c[1]))
+    return out
+
+
+def rsx_engagement_features(algorithm, cand, map_ids, map_embeddings, groups):
+    """Scorer.computeSimilarityScoresPerTweet + Scorer.avg / max (twistlyfeatures/Scorer.scala:157-369,426-429)
+    for one candidate embedding `cand` (or None).  map_ids[m]: the id list scored through map m (duplicates
+    kept); map_embeddings[m]: id -> embedding; groups: (map, [signal ids in order]).  Returns (avg, max) per
+    group with None for an empty fold."""
+    results = []  # per map: list of ScoreResult(id, Option[score]) -- getTweetScores / getUserScores
+    for ids, emb in zip(map_ids, map_embeddings):
+        rs = []
+        for i in ids:
+            e = emb.get(i)
+            rs.append((i, None if cand is None or e is None else pair_score(algorithm, e[0], e[1], cand[0], cand[1])))
+        results.append(rs)
+    out = []
+    for m, signal_ids in groups:
+        by_id = {}
+        for i, s in results[m]:  # groupBy(_.id)
+            by_id.setdefault(i, []).append(s)
+        vals = [s for i in signal_ids for s in by_id.get(i, []) if s is not None]
+        if not vals:
+            out.append((None, None))
+            continue
+        total = 0.0
+        for v in vals:
+            total = total + v
+        mx = 0.0
+        for v in vals:
+            mx = max(mx, v)
+        out.append((total / len(vals), mx))
+    return out

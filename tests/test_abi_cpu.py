@@ -41,6 +41,9 @@ def test_version_and_error_paths(pkg):
     assert lib.sann_batch_run(None, None) == 1
     assert lib.sann_batch_destroy(None) == 0
     assert lib.sann_index_destroy(None) == 0
+    rl = pkg.representation_scorer._lib()
+    assert rl.rsx_store_pair_scores(None, None, 2, 1, None, None, None, None) == 1  # RSX_EINVAL before any HIP call
+    assert rl.rsx_store_destroy(None) == 0
     dl = pkg.dense_ann._lib()
     assert dl.dann_index_build(0, 0, 10, 16, None, None, C.byref(h)) == 1  # DANN_EINVAL before any HIP call
     assert dl.dann_search(None, 1, None, 1, None, None, None) == 1

@@ -10,6 +10,8 @@
 // fp64 accumulation order is part of the semantics.  HBM-bound: (n_a + n_b) * 12 B per pair.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -27,30 +29,21 @@ __device__ inline double sum_sq(const double *v, int n) {
   return s;
 }
 
-__global__ __launch_bounds__(256) void rsx_pair_kernel(int alg, int n_pairs, const int64_t *ao, const int32_t *ac,
-                                                       const double *as, const int64_t *bo, const int32_t *bc,
-                                                       const double *bs, double *out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_pairs) return;
-  const int64_t a0 = ao[i], b0 = bo[i];
-  const int n1 = (int)(ao[i + 1] - a0), n2 = (int)(bo[i + 1] - b0);
-  const int32_t *c1 = ac + a0, *c2 = bc + b0;
-  const double *s1 = as + a0, *s2 = bs + b0;
-  double r;
+// one pair: the reference's arithmetic, operation for operation.  NaN for an unknown algorithm.
+__device__ double pair_score(int alg, const int32_t *c1, const double *s1, int n1, const int32_t *c2, const double *s2,
+                             int n2) {
   if (alg == 3) {  // jaccard
-    if (n1 == 0 || n2 == 0) {
-      r = 0.0;
-    } else {
-      int i1 = 0, i2 = 0, inter = 0;
-      while (i1 < n1 && i2 < n2) {
-        const int x = c1[i1], y = c2[i2];
-        inter += x == y;
-        i1 += x <= y;
-        i2 += y <= x;
-      }
-      r = (double)inter / (double)(n1 + n2 - inter);
+    if (n1 == 0 || n2 == 0) return 0.0;
+    int i1 = 0, i2 = 0, inter = 0;
+    while (i1 < n1 && i2 < n2) {
+      const int x = c1[i1], y = c2[i2];
+      inter += x == y;
+      i1 += x <= y;
+      i2 += y <= x;
     }
-  } else if (alg == 4 || alg == 5) {  // euclidean / manhattan over the union, ascending id
+    return (double)inter / (double)(n1 + n2 - inter);
+  }
+  if (alg == 4 || alg == 5) {  // euclidean / manhattan over the union, ascending id
     int i1 = 0, i2 = 0;
     double sum = 0.0;
     while (i1 < n1 || i2 < n2) {
@@ -61,41 +54,159 @@ __global__ __launch_bounds__(256) void rsx_pair_kernel(int alg, int n_pairs, con
       const double d = fabs(x - y);
       sum = (alg == 4) ? sum + d * d : sum + d;
     }
-    r = (alg == 4) ? sqrt(sum) : sum;
-  } else {
-    double na = 1.0, nb = 1.0;
-    bool norm = false;
-    if (alg == 2) { na = sqrt(sum_sq(s1, n1)); nb = sqrt(sum_sq(s2, n2)); norm = true; }
-    else if (alg == 6) { na = sann::strict_log(sum_sq(s1, n1) + 1); nb = sann::strict_log(sum_sq(s2, n2) + 1); norm = true; }
-    else if (alg == 7) { na = pow(sum_sq(s1, n1), 0.3); nb = pow(sum_sq(s2, n2), 0.3); norm = true; }
-    else if (alg != 1) { out[i] = __builtin_nan(""); return; }
-    const bool da = norm && na != 0, db = norm && nb != 0;  // applyNormArray leaves the array alone when norm == 0
-    int i1 = 0, i2 = 0;
-    double product = 0.0;
-    while (i1 < n1 && i2 < n2) {
-      const int x = c1[i1], y = c2[i2];
-      if (x == y) {
-        const double u = da ? s1[i1] / na : s1[i1];
-        const double v = db ? s2[i2] / nb : s2[i2];
-        product += u * v;
-        i1++;
-        i2++;
-      } else if (x > y) {
-        i2++;
-      } else {
-        i1++;
+    return (alg == 4) ? sqrt(sum) : sum;
+  }
+  double na = 1.0, nb = 1.0;
+  bool norm = false;
+  if (alg == 2) { na = sqrt(sum_sq(s1, n1)); nb = sqrt(sum_sq(s2, n2)); norm = true; }
+  else if (alg == 6) { na = sann::strict_log(sum_sq(s1, n1) + 1); nb = sann::strict_log(sum_sq(s2, n2) + 1); norm = true; }
+  else if (alg == 7) { na = pow(sum_sq(s1, n1), 0.3); nb = pow(sum_sq(s2, n2), 0.3); norm = true; }
+  else if (alg != 1) return __builtin_nan("");
+  const bool da = norm && na != 0, db = norm && nb != 0;  // applyNormArray leaves the array alone when norm == 0
+  int i1 = 0, i2 = 0;
+  double product = 0.0;
+  while (i1 < n1 && i2 < n2) {
+    const int x = c1[i1], y = c2[i2];
+    if (x == y) {
+      const double u = da ? s1[i1] / na : s1[i1];
+      const double v = db ? s2[i2] / nb : s2[i2];
+      product += u * v;
+      i1++;
+      i2++;
+    } else if (x > y) {
+      i2++;
+    } else {
+      i1++;
+    }
+  }
+  return product;
+}
+
+__global__ __launch_bounds__(256) void rsx_pair_kernel(int alg, int n_pairs, const int64_t *ao, const int32_t *ac,
+                                                       const double *as, const int64_t *bo, const int32_t *bc,
+                                                       const double *bs, double *out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pairs) return;
+  const int64_t a0 = ao[i], b0 = bo[i];
+  out[i] = pair_score(alg, ac + a0, as + a0, (int)(ao[i + 1] - a0), bc + b0, bs + b0, (int)(bo[i + 1] - b0));
+}
+
+// ---- resident embedding stores (R1 hydration, R4 list scores, R5 engagement aggregates) ----
+struct StoreView {
+  const int64_t *off;
+  const int32_t *cid;
+  const double *sc;
+};
+
+// pair i = (row a_rows[i] of A, row b_rows[i] of B); a row < 0 is an embedding the store does not hold:
+// the score is None (PairScoreStore.get, score/ScoreStore.scala:41-54)
+__global__ __launch_bounds__(256) void rsx_rows_kernel(int alg, int n_pairs, StoreView A, const int32_t *a_rows, StoreView B,
+                                                       const int32_t *b_rows, double *out, uint8_t *present) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pairs) return;
+  const int ra = a_rows[i], rb = b_rows[i];
+  if (ra < 0 || rb < 0) {
+    out[i] = 0.0;
+    present[i] = 0;
+    return;
+  }
+  const int64_t a0 = A.off[ra], b0 = B.off[rb];
+  out[i] = pair_score(alg, A.cid + a0, A.sc + a0, (int)(A.off[ra + 1] - a0), B.cid + b0, B.sc + b0, (int)(B.off[rb + 1] - b0));
+  present[i] = 1;
+}
+
+// Scorer.computeSimilarityScoresPerTweet (representation-scorer/.../twistlyfeatures/Scorer.scala:157-369)
+// for one (candidate, signal group): walk the group's signals in order, each contributing its score
+// once per occurrence of its id in the hydrated id list (the groupBy(_.id) of :146-147 keeps every
+// duplicate), skip the missing ones, then avg = sum / size with a left-fold sum and max folded from 0.0
+// (Scorer.scala:426-429).
+constexpr int RSX_MAX_MAPS = 4;
+struct GroupArgs {
+  StoreView cand;
+  StoreView map[RSX_MAX_MAPS];
+  const int32_t *cand_rows;     // [n_cand]
+  const int32_t *group_map;     // [n_groups]
+  const int64_t *group_off;     // [n_groups + 1]
+  const int32_t *member_rows;   // row in the group's map store, < 0 = not hydrated
+  const int32_t *member_mult;   // occurrences of the member's id in the map's id list
+  double *out_avg, *out_max;
+  int32_t *out_count;
+  int n_cand, n_groups, alg;
+};
+
+__global__ __launch_bounds__(256) void rsx_group_kernel(GroupArgs g) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.n_cand * g.n_groups) return;
+  const int c = i / g.n_groups, grp = i % g.n_groups;
+  const int rc = g.cand_rows[c];
+  double sum = 0.0, mx = 0.0;
+  int cnt = 0;
+  if (rc >= 0) {
+    const StoreView S = g.map[g.group_map[grp]];
+    const int64_t c0 = g.cand.off[rc];
+    const int nc = (int)(g.cand.off[rc + 1] - c0);
+    for (int64_t m = g.group_off[grp]; m < g.group_off[grp + 1]; ++m) {
+      const int rs = g.member_rows[m];
+      if (rs < 0) continue;
+      const int64_t s0 = S.off[rs];
+      const double v = pair_score(g.alg, S.cid + s0, S.sc + s0, (int)(S.off[rs + 1] - s0), g.cand.cid + c0, g.cand.sc + c0, nc);
+      for (int r = 0; r < g.member_mult[m]; ++r) {
+        sum = sum + v;
+        mx = fmax(mx, v);
+        cnt++;
       }
     }
-    r = product;
   }
-  out[i] = r;
+  g.out_count[i] = cnt;
+  g.out_avg[i] = cnt ? sum / (double)cnt : 0.0;
+  g.out_max[i] = mx;
 }
 
 struct Buf {
   void *p = nullptr;
   ~Buf() { if (p) (void)hipFree(p); }
+  hipError_t put(const void *src, size_t bytes) {
+    hipError_t r = hipMalloc(&p, bytes ? bytes : 8);
+    if (r == hipSuccess && bytes && src) r = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+    return r;
+  }
 };
 
+}  // namespace
+
+struct rsx_store {
+  int device = 0;
+  std::vector<int64_t> ids;  // ascending; row = position
+  Buf off, cid, sc;
+  StoreView view() const { return StoreView{(const int64_t *)off.p, (const int32_t *)cid.p, (const double *)sc.p}; }
+  int32_t row_of(int64_t id) const {
+    auto it = std::lower_bound(ids.begin(), ids.end(), id);
+    return (it == ids.end() || *it != id) ? -1 : (int32_t)(it - ids.begin());
+  }
+};
+
+namespace {
+#define RSX_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return rsx_fail(RSX_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+int rows_scores(const rsx_store *A, const rsx_store *B, int alg, int32_t n, const std::vector<int32_t> &ra,
+                const std::vector<int32_t> &rb, double *out_scores, uint8_t *out_present) {
+  RSX_TRY(hipSetDevice(A->device));
+  Buf da, db, dout, dpres;
+  RSX_TRY(da.put(ra.data(), (size_t)n * 4));
+  RSX_TRY(db.put(rb.data(), (size_t)n * 4));
+  RSX_TRY(dout.put(nullptr, (size_t)n * 8));
+  RSX_TRY(dpres.put(nullptr, (size_t)n));
+  hipLaunchKernelGGL(rsx_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, alg, n, A->view(), (const int32_t *)da.p,
+                     B->view(), (const int32_t *)db.p, (double *)dout.p, (uint8_t *)dpres.p);
+  RSX_TRY(hipGetLastError());
+  RSX_TRY(hipMemcpy(out_scores, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  RSX_TRY(hipMemcpy(out_present, dpres.p, (size_t)n, hipMemcpyDeviceToHost));
+  return RSX_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -162,6 +273,134 @@ int rsx_pair_scores(int32_t device, int32_t algorithm, int32_t n_pairs, const in
   if (rc != RSX_OK) return rc;
   e = hipMemcpy(out_scores, dout.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost);
   if (e != hipSuccess) return rsx_fail(RSX_EDEVICE, hipGetErrorString(e));
+  return RSX_OK;
+}
+
+int rsx_store_build(int32_t device, int64_t n, const int64_t *ids, const int64_t *offsets, const int32_t *cluster_ids,
+                    const double *scores, rsx_store_t **out) {
+  if (!out || n < 0 || (n > 0 && (!ids || !offsets))) return rsx_fail(RSX_EINVAL, "NULL argument");
+  if (n >= 0x7fffffff) return rsx_fail(RSX_EINVAL, "too many embeddings");
+  const int64_t total = n ? offsets[n] : 0;
+  if (n && offsets[0] != 0) return rsx_fail(RSX_EINVAL, "offsets must start at 0");
+  if (total > 0 && (!cluster_ids || !scores)) return rsx_fail(RSX_EINVAL, "NULL embedding arrays");
+  for (int64_t i = 0; i < n; i++) {
+    if (i && ids[i] <= ids[i - 1]) return rsx_fail(RSX_EINVAL, "store ids must be strictly ascending");
+    if (offsets[i + 1] < offsets[i]) return rsx_fail(RSX_EINVAL, "offsets must not decrease");
+    for (int64_t j = offsets[i]; j < offsets[i + 1]; j++) {
+      if (!(scores[j] > 0.0) || (j > offsets[i] && cluster_ids[j] <= cluster_ids[j - 1]))
+        return rsx_fail(RSX_EINVAL, "embeddings must be sorted by cluster id, unique, with scores > 0");
+    }
+  }
+  std::unique_ptr<rsx_store> st(new rsx_store);
+  st->device = device;
+  st->ids.assign(ids, ids + n);
+  RSX_TRY(hipSetDevice(device));
+  const int64_t zero = 0;
+  RSX_TRY(st->off.put(n ? offsets : &zero, ((size_t)n + 1) * 8));
+  RSX_TRY(st->cid.put(cluster_ids, (size_t)total * 4));
+  RSX_TRY(st->sc.put(scores, (size_t)total * 8));
+  *out = st.release();
+  return RSX_OK;
+}
+
+int rsx_store_destroy(rsx_store_t *store) {
+  delete store;
+  return RSX_OK;
+}
+
+int rsx_store_pair_scores(const rsx_store_t *a, const rsx_store_t *b, int32_t algorithm, int32_t n_pairs,
+                          const int64_t *a_ids, const int64_t *b_ids, double *out_scores, uint8_t *out_present) {
+  if (!a || !b || n_pairs < 0) return rsx_fail(RSX_EINVAL, "NULL store or n_pairs < 0");
+  if (algorithm < 1 || algorithm > 7) return rsx_fail(RSX_EINVAL, "unknown pair scoring algorithm");
+  if (a->device != b->device) return rsx_fail(RSX_EINVAL, "stores live on different devices");
+  if (n_pairs == 0) return RSX_OK;
+  if (!a_ids || !b_ids || !out_scores || !out_present) return rsx_fail(RSX_EINVAL, "NULL argument");
+  std::vector<int32_t> ra((size_t)n_pairs), rb((size_t)n_pairs);
+  for (int32_t i = 0; i < n_pairs; i++) {
+    ra[(size_t)i] = a->row_of(a_ids[i]);
+    rb[(size_t)i] = b->row_of(b_ids[i]);
+  }
+  return rows_scores(a, b, algorithm, n_pairs, ra, rb, out_scores, out_present);
+}
+
+int rsx_store_list_scores(const rsx_store_t *targets, const rsx_store_t *candidates, int32_t algorithm, int64_t target_id,
+                          int32_t n_candidates, const int64_t *candidate_ids, double *out_scores, uint8_t *out_present) {
+  if (!targets || !candidates || n_candidates < 0) return rsx_fail(RSX_EINVAL, "NULL store or n_candidates < 0");
+  if (algorithm < 1 || algorithm > 7) return rsx_fail(RSX_EINVAL, "unknown pair scoring algorithm");
+  if (targets->device != candidates->device) return rsx_fail(RSX_EINVAL, "stores live on different devices");
+  if (n_candidates == 0) return RSX_OK;
+  if (!candidate_ids || !out_scores || !out_present) return rsx_fail(RSX_EINVAL, "NULL argument");
+  std::vector<int32_t> ra((size_t)n_candidates, targets->row_of(target_id)), rb((size_t)n_candidates);
+  for (int32_t i = 0; i < n_candidates; i++) rb[(size_t)i] = candidates->row_of(candidate_ids[i]);
+  return rows_scores(targets, candidates, algorithm, n_candidates, ra, rb, out_scores, out_present);
+}
+
+int rsx_store_group_features(const rsx_store_t *candidates, int32_t algorithm, int32_t n_candidates,
+                             const int64_t *candidate_ids, int32_t n_maps, const rsx_store_t *const *map_stores,
+                             const int64_t *map_id_offsets, const int64_t *map_ids, int32_t n_groups,
+                             const int32_t *group_map, const int64_t *group_offsets, const int64_t *group_member_ids,
+                             double *out_avg, double *out_max, int32_t *out_count) {
+  if (!candidates || n_candidates < 0 || n_groups < 0) return rsx_fail(RSX_EINVAL, "NULL store or negative size");
+  if (algorithm < 1 || algorithm > 7) return rsx_fail(RSX_EINVAL, "unknown pair scoring algorithm");
+  if (n_maps < 1 || n_maps > RSX_MAX_MAPS) return rsx_fail(RSX_EINVAL, "n_maps must be in 1..4");
+  if (n_candidates == 0 || n_groups == 0) return RSX_OK;
+  if (!candidate_ids || !map_stores || !map_id_offsets || !group_map || !group_offsets || !out_avg || !out_max || !out_count)
+    return rsx_fail(RSX_EINVAL, "NULL argument");
+  if ((int64_t)n_candidates * n_groups >= 0x7fffffff) return rsx_fail(RSX_EINVAL, "n_candidates * n_groups too large");
+  for (int m = 0; m < n_maps; m++)
+    if (!map_stores[m] || map_stores[m]->device != candidates->device) return rsx_fail(RSX_EINVAL, "bad map store");
+  const int64_t n_members = group_offsets[n_groups];
+  if (n_members > 0 && (!group_member_ids || !map_ids)) return rsx_fail(RSX_EINVAL, "NULL member / map ids");
+  // multiplicity of every id in its map's hydrated id list (Scorer.scala:139-147: one ScoreResult per
+  // occurrence, grouped by id)
+  std::vector<std::vector<int64_t>> sorted((size_t)n_maps);
+  for (int m = 0; m < n_maps; m++) {
+    sorted[(size_t)m].assign(map_ids + map_id_offsets[m], map_ids + map_id_offsets[m + 1]);
+    std::sort(sorted[(size_t)m].begin(), sorted[(size_t)m].end());
+  }
+  std::vector<int32_t> rows((size_t)n_members), mult((size_t)n_members), crow((size_t)n_candidates);
+  for (int g = 0; g < n_groups; g++) {
+    const int m = group_map[g];
+    if (m < 0 || m >= n_maps) return rsx_fail(RSX_EINVAL, "group_map out of range");
+    if (group_offsets[g + 1] < group_offsets[g]) return rsx_fail(RSX_EINVAL, "group offsets must not decrease");
+    for (int64_t j = group_offsets[g]; j < group_offsets[g + 1]; j++) {
+      const int64_t id = group_member_ids[j];
+      auto r = std::equal_range(sorted[(size_t)m].begin(), sorted[(size_t)m].end(), id);
+      mult[(size_t)j] = (int32_t)(r.second - r.first);  // 0: the signal's id was never scored -> contributes nothing
+      rows[(size_t)j] = map_stores[m]->row_of(id);
+    }
+  }
+  for (int32_t i = 0; i < n_candidates; i++) crow[(size_t)i] = candidates->row_of(candidate_ids[i]);
+  RSX_TRY(hipSetDevice(candidates->device));
+  const size_t nout = (size_t)n_candidates * n_groups;
+  Buf dcrow, dgmap, dgoff, drows, dmult, davg, dmax, dcnt;
+  RSX_TRY(dcrow.put(crow.data(), crow.size() * 4));
+  RSX_TRY(dgmap.put(group_map, (size_t)n_groups * 4));
+  RSX_TRY(dgoff.put(group_offsets, ((size_t)n_groups + 1) * 8));
+  RSX_TRY(drows.put(rows.data(), rows.size() * 4));
+  RSX_TRY(dmult.put(mult.data(), mult.size() * 4));
+  RSX_TRY(davg.put(nullptr, nout * 8));
+  RSX_TRY(dmax.put(nullptr, nout * 8));
+  RSX_TRY(dcnt.put(nullptr, nout * 4));
+  GroupArgs g;
+  g.cand = candidates->view();
+  for (int m = 0; m < RSX_MAX_MAPS; m++) g.map[m] = map_stores[m < n_maps ? m : 0]->view();
+  g.cand_rows = (const int32_t *)dcrow.p;
+  g.group_map = (const int32_t *)dgmap.p;
+  g.group_off = (const int64_t *)dgoff.p;
+  g.member_rows = (const int32_t *)drows.p;
+  g.member_mult = (const int32_t *)dmult.p;
+  g.out_avg = (double *)davg.p;
+  g.out_max = (double *)dmax.p;
+  g.out_count = (int32_t *)dcnt.p;
+  g.n_cand = n_candidates;
+  g.n_groups = n_groups;
+  g.alg = algorithm;
+  hipLaunchKernelGGL(rsx_group_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, 0, g);
+  RSX_TRY(hipGetLastError());
+  RSX_TRY(hipMemcpy(out_avg, davg.p, nout * 8, hipMemcpyDeviceToHost));
+  RSX_TRY(hipMemcpy(out_max, dmax.p, nout * 8, hipMemcpyDeviceToHost));
+  RSX_TRY(hipMemcpy(out_count, dcnt.p, nout * 4, hipMemcpyDeviceToHost));
   return RSX_OK;
 }
 
