@@ -55,6 +55,16 @@ extern "C" {
 #define SANN_VARIANT_ORIGINAL 0
 #define SANN_VARIANT_OPTIMIZED 1
 #define SANN_VARIANT_EXPERIMENTAL 2
+/* LEGACY  src/scala/com/twitter/simclusters_v2/candidate_source/SimClustersANNCandidateSource.scala:107-181
+ *         (the in-process candidate source cr-mixer used before the service): same accumulate;
+ *         no "175200 h" rule in the age window (:113); no minScore filter (min_score is ignored);
+ *         ann_algorithm carries its (enablePartialNormalization, rankingAlgorithm) pair:
+ *         DOT_PRODUCT = no normalisation, COSINE = partial normalisation, LOG_COSINE = partial
+ *         normalisation in the "log" form, which divides by l2norm rather than logNorm (:167-169).
+ *         max_num_results above 1000 is refused (SANN_ELIMIT).  The optional heavy re-rank (:182-200,
+ *         HeavyRanker.scala:32-77) is this call with max_num_results = maxReRankingCandidates followed
+ *         by rsx_store_list_scores; see the Python mirror LegacySimClustersANNCandidateSource. */
+#define SANN_VARIANT_LEGACY 3
 
 /* SimClustersANNConfig, simClustersAnn.thrift:18-27 -- field for field. */
 typedef struct sann_config {

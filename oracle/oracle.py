@@ -92,8 +92,9 @@ def sann_query(emb_ids, emb_scores, source_tweet_id, cfg, now_ms, cluster_ids, l
     tweet_ids = np.ascontiguousarray(tweet_ids, np.int64)
     scores = np.ascontiguousarray(scores, np.float64)
     so = None if scan_order is None else np.ascontiguousarray(scan_order, np.int32)
-    out_ids = np.zeros(1000, np.int64)
-    out_scores = np.zeros(1000, np.float64)
+    cap = max(1000, int(getattr(cfg, "maxNumResults", 1000)) if variant == 3 else 1000)
+    out_ids = np.zeros(cap, np.int64)
+    out_scores = np.zeros(cap, np.float64)
     msz = C.c_int32()
     c = make_config(cfg)
     n = L.oracle_sann_query(int(variant), len(emb_ids), _p(emb_ids), _p(emb_scores),

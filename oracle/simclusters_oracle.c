@@ -386,6 +386,14 @@ static int64_t find_list(int32_t n_lists, const int32_t *list_cluster_ids, int32
  *   variant 0 "original"     SANN/ApproximateCosineSimilarity.scala:57-128
  *   variant 1 "optimized"    SANN/OptimizedApproximateCosineSimilarity.scala:37-111
  *   variant 2 "experimental" SANN/ExperimentalApproximateCosineSimilarity.scala:41-130
+ *   variant 3 "legacy"       src/scala/com/twitter/simclusters_v2/candidate_source/
+ *                            SimClustersANNCandidateSource.scala:107-181 (fetchCandidates): the age
+ *                            window has no "175200 h = unbounded" rule (:113-114); the config's
+ *                            (enablePartialNormalization, rankingAlgorithm) arrive folded into
+ *                            ann_algorithm -- 1 = no normalisation (raw dot), 2 = partial
+ *                            normalisation, 3 = partial normalisation with the "log" form, which
+ *                            divides by l2norm, NOT logNorm (:167-169); no minScore filter and no
+ *                            1000 cap before the sort (:177-180, reranking :195 takes maxNumResults).
  * preceded by the cluster selection of SimClustersANNCandidateSource.fetchCandidates
  * (SANN/SimClustersANNCandidateSource.scala:72-80) when scan_order == NULL.
  *
@@ -407,6 +415,8 @@ int32_t oracle_sann_query(int32_t variant, int32_t n_emb, const int32_t *emb_ids
   oracle_embedding *emb = oracle_embedding_build(n_emb, emb_ids, emb_scores, -1);
   int64_t earliest, latest;
   oracle_age_window(cfg, now_ms, &earliest, &latest);
+  if (variant == 3) /* legacy :113: always SnowflakeId.firstIdFor(now - maxTweetCandidateAge) */
+    earliest = oracle_snowflake_first_id_for(now_ms - (int64_t)cfg->max_tweet_candidate_age_hours * 3600000ll);
 
   /* keys of clusterTweetsMap, in iteration order */
   int32_t n_scan;
@@ -453,7 +463,7 @@ int32_t oracle_sann_query(int32_t variant, int32_t n_emb, const int32_t *emb_ids
     for (int64_t i = 0; i < lim; i++) {
       int64_t t = tid[i];
       double s = sc[i];
-      int excl = (variant == 0) ? (has_source_tweet && t == source_tweet_id) /* :90 */
+      int excl = (variant == 0 || variant == 3) ? (has_source_tweet && t == source_tweet_id) /* :90; legacy :139 */
                                 : (t == src_excl);                            /* Optimized :67 */
       if (!excl && t >= earliest && t <= latest) { /* :90-91 */
         cand *e = candmap_get_or_insert(&map, t);
@@ -469,6 +479,16 @@ int32_t oracle_sann_query(int32_t variant, int32_t n_emb, const int32_t *emb_ids
   int32_t nres = 0;
   for (int32_t i = 0; i < map.n; i++) {
     double score = map.e[i].dot, nsq = map.e[i].nsq, p;
+    if (variant == 3) { /* legacy :160-174 */
+      switch (cfg->ann_algorithm) {
+      case 3: p = score / l2 / oracle_strict_log(1 + nsq); break;
+      case 2: p = score / l2 / sqrt(nsq); break;
+      case 1: p = score; break;
+      default: p = NAN; break;
+      }
+      res[nres].id = map.e[i].id; res[nres].score = p; nres++;
+      continue;
+    }
     switch (cfg->ann_algorithm) { /* :111-119 */
     case 3: p = score / ln / oracle_strict_log(1 + nsq); break;
     case 2: p = score / l2 / sqrt(nsq); break;
@@ -480,6 +500,7 @@ int32_t oracle_sann_query(int32_t variant, int32_t n_emb, const int32_t *emb_ids
   }
   qsort(res, (size_t)nres, sizeof(scored), cmp_scored);
   int32_t k = cfg->max_num_results < 1000 ? cfg->max_num_results : 1000; /* :41,:127 */
+  if (variant == 3) k = cfg->max_num_results; /* legacy: plain take(maxNumResults); the caller sizes the outputs */
   if (k < 0) k = 0;
   if (nres > k) nres = k;
   for (int32_t i = 0; i < nres; i++) { out_ids[i] = res[i].id; out_scores[i] = res[i].score; }

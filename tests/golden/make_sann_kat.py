@@ -136,6 +136,33 @@ cases.append(dict(name="accum_order_321", emb=[[1, 3.0], [2, 3.0], [3, 3.0]], so
                   scan_keys=[3, 2, 1], lists={"1": [[5, 0.1]], "2": [[5, 0.2]], "3": [[5, 0.3]]}, config=cfg(alg=1),
                   expect=[[5, hx((0.0 + c + b) + a)]], map_size=1, ulp=0))
 
+# --- 12. legacy candidate source (variant 3), simclusters_v2/candidate_source/SimClustersANNCandidateSource.scala:107-181
+#     ann_algorithm carries (enablePartialNormalization, rankingAlgorithm): 1 = raw dot, 2 = dot/l2norm/sqrt(nsq),
+#     3 = dot / l2norm / log(1 + nsq)  -- l2norm, not logNorm (:167-169); no minScore filter (:177-180)
+emb = [[1, 3.0], [2, 4.0]]
+lists = {"1": [[10, 2.0], [11, 1.0]], "2": [[10, 1.0], [12, 5.0]]}
+cases.append(dict(name="legacy_log_divides_by_l2norm", emb=emb, lists=lists, source=None, variant=3, now_ms=NOW,
+                  config=cfg(alg=3),  # default maxAge 175200 h: now - 20 y is before the Snowflake epoch, lower bound < 0
+                  # 20/5/ln26 = 1.2277 > 10/5/ln6 = 1.1162 > 3/5/ln2 = 0.8656
+                  expect=[[12, hx(d12 / l2 / math.log(1 + n12))], [10, hx(d10 / l2 / math.log(1 + n10))],
+                          [11, hx(d11 / l2 / math.log(1 + n11))]], map_size=3, ulp=4))
+cases.append(dict(name="legacy_ignores_min_score", emb=emb, lists=lists, source=None, variant=3, now_ms=NOW,
+                  config=cfg(alg=2, min_score=0.95),
+                  expect=[[10, hx(d10 / l2 / math.sqrt(n10))], [12, hx(d12 / l2 / math.sqrt(n12))],
+                          [11, hx(d11 / l2 / math.sqrt(n11))]], map_size=3, ulp=0))
+cases.append(dict(name="legacy_no_normalisation", emb=emb, lists=lists, source=11, variant=3, now_ms=NOW,
+                  config=cfg(alg=1, k=1),
+                  expect=[[12, hx(d12)]], map_size=2, ulp=0))   # source tweet 11 excluded (:139), take(1)
+# no "175200 h = unbounded" rule (:113): with now far enough in the future the lower bound is a real id.
+# now - 175200 h = EPOCH + 1000 ms -> earliest = 1000 << 22; the same case under variant 0 keeps both tweets.
+FUTURE = EPOCH + 175200 * 3600_000 + 1000
+old_t, new_t = (999 << 22) + 5, (1000 << 22)
+lists_w = {"1": [[old_t, 2.0], [new_t, 1.0]]}
+cases.append(dict(name="legacy_window_has_a_lower_bound", emb=[[1, 3.0]], lists=lists_w, source=None, variant=3, now_ms=FUTURE,
+                  config=cfg(alg=1, max_age=175200), expect=[[new_t, hx(1.0 * 3.0)]], map_size=1, ulp=0))
+cases.append(dict(name="original_175200h_is_unbounded", emb=[[1, 3.0]], lists=lists_w, source=None, variant=0, now_ms=FUTURE,
+                  config=cfg(alg=1, max_age=175200), expect=[[old_t, hx(2.0 * 3.0)], [new_t, hx(1.0 * 3.0)]], map_size=2, ulp=0))
+
 # --- RSX pair scores (SimClustersEmbedding.scala:194-224,235-243,301-321; score.thrift:14-22)
 A = [[1, 3.0], [2, 4.0]]
 B = [[2, 1.0], [3, 2.0], [1, 2.0]]

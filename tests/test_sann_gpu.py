@@ -368,3 +368,77 @@ def test_many_scan_clusters_overflow_to_general(pkg, oracle, small):
     check_against_oracle(pkg, oracle, co, e_offs, e_c, e_s, cfg, out)
     assert st.n_fallback_units == 16
     index.close()
+
+
+@pytest.mark.parametrize("alg", [1, 2, 3])
+def test_legacy_variant_bit_exact(pkg, oracle, small, alg):
+    """SANN_VARIANT_LEGACY (simclusters_v2/candidate_source/SimClustersANNCandidateSource.scala:107-181):
+    no minScore filter, real lower bound of the age window, 'log' form over l2norm, source exclusion."""
+    co, offs, cids, scs = small
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=8)
+    nq = len(offs) - 1
+    rng = np.random.default_rng(alg)
+    sources = [int(co.tweet_ids[rng.integers(len(co.tweet_ids))]) if q % 3 == 0 else None for q in range(nq)]
+    cfgs = [pkg.SimClustersANNConfig(maxNumResults=150 + 10 * q, minScore=0.5, maxTopTweetsPerCluster=200, maxScanClusters=40,
+                                     maxTweetCandidateAgeHours=[175200, 12, 24][q % 3], minTweetCandidateAgeHours=q % 2,
+                                     annAlgorithm=pkg.ScoringAlgorithm(alg)) for q in range(nq)]
+    src = np.array([0 if s is None else s for s in sources], np.int64)
+    has = np.array([0 if s is None else 1 for s in sources], np.uint8)
+    out, _ = run_batch(pkg, index, co, offs, cids, scs, cfgs, variant=3, source_tweet_ids=src, has_source_tweet=has)
+    check_against_oracle(pkg, oracle, co, offs, cids, scs, cfgs, out, variant=3, sources=sources)
+    assert out[2].max() > 100, "minScore 0.5 would have emptied a cosine result under the service variants"
+    # refused inputs
+    bad = pkg.SimClustersANNConfig(maxNumResults=10, annAlgorithm=pkg.ScoringAlgorithm(4))
+    with pytest.raises(pkg.simclusters_ann.SannError):
+        pkg.QueryBatch(index, offs, cids, scs, bad, now_ms=co.now_ms, variant=pkg.Variant.legacy)
+    big = pkg.SimClustersANNConfig(maxNumResults=1001)
+    with pytest.raises(pkg.simclusters_ann.SannError):
+        pkg.QueryBatch(index, offs, cids, scs, big, now_ms=co.now_ms, variant=pkg.Variant.legacy)
+    index.close()
+
+
+def test_legacy_source_with_heavy_ranking(pkg, oracle, small):
+    """fetchCandidates -> take(maxReRankingCandidates) -> HeavyRanker (pair score >= minScore) -> sort -> take
+    (SimClustersANNCandidateSource.scala:182-200, HeavyRanker.scala:32-77), device light rank + device pair scorer,
+    against the same composition of the two oracles."""
+    co, offs, cids, scs = small
+    rs = pkg.representation_scorer
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=8)
+    rng = np.random.default_rng(5)
+    emb = [(int(c), float(s)) for c, s in zip(cids[offs[2]:offs[3]], scs[offs[2]:offs[3]])]
+    lcfg = pkg.LegacySimClustersANNConfig(maxNumResults=60, maxTweetCandidateAgeHours=175200, minScore=0.02, enableHeavyRanking=True,
+                                          rankingAlgorithm=6, maxReRankingCandidates=300, maxTopTweetsPerCluster=200, maxScanClusters=40)
+    # light ranking by the oracle (legacy log form), then tweet embeddings for ~90 % of those candidates
+    ocfg = pkg.SimClustersANNConfig(maxNumResults=300, maxTopTweetsPerCluster=200, maxScanClusters=40, maxTweetCandidateAgeHours=175200,
+                                    annAlgorithm=pkg.ScoringAlgorithm.LogCosineSimilarity)
+    l_ids, l_sc, _ = oracle.sann_query([c for c, _ in emb], [s for _, s in emb], None, ocfg, co.now_ms, co.cluster_ids,
+                                       co.list_offsets, co.tweet_ids, co.scores, variant=3)
+    assert len(l_ids) == 300
+    tweets = {}
+    for t in l_ids.tolist():
+        if rng.random() < 0.9:
+            n = int(rng.integers(1, 12))
+            tweets[t] = [(int(c), float(s)) for c, s in zip(rng.choice(cids[offs[2]:offs[3]], n, replace=False), rng.random(n) + 0.05)]
+    src_store, tw_store = rs.EmbeddingStore({77: emb}), rs.EmbeddingStore(tweets)
+    source = pkg.LegacySimClustersANNCandidateSource(index, src_store, tw_store, now_ms=co.now_ms)
+    got = source.get(emb, None, lcfg, source_internal_id=77)
+    se = rs.simclusters_embedding(emb)
+    want = []
+    for t in l_ids.tolist():
+        if t in tweets:
+            te = rs.simclusters_embedding(tweets[t])
+            s = oracle.pair_score(6, se[0], se[1], te[0], te[1])
+            if s >= lcfg.minScore:
+                want.append((t, s))
+    want.sort(key=lambda x: (-x[1], x[0]))
+    want = want[:60]
+    assert len(got) == len(want) == 60
+    assert [t for t, _ in got] == [t for t, _ in want]
+    assert all(abs(a[1] - b[1]) <= 1e-15 * abs(b[1]) for a, b in zip(got, want))
+    # without heavy ranking: the light ranking itself, cut at maxNumResults
+    lcfg2 = pkg.LegacySimClustersANNConfig(maxNumResults=60, maxTweetCandidateAgeHours=175200, rankingAlgorithm=6,
+                                           maxTopTweetsPerCluster=200, maxScanClusters=40)
+    light = source.get(emb, None, lcfg2)
+    assert [t for t, _ in light] == l_ids[:60].tolist()
+    assert np.array_equal(np.array([s for _, s in light]).view(np.int64), l_sc[:60].view(np.int64))
+    src_store.close(); tw_store.close(); index.close()

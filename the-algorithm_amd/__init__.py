@@ -8,6 +8,8 @@ from . import corpus, dense_ann, representation_scorer, sharding, simclusters_an
 from .simclusters_ann import (  # noqa: F401
     ApproximateCosineSimilarity,
     ClusterTweetIndex,
+    LegacySimClustersANNCandidateSource,
+    LegacySimClustersANNConfig,
     QueryBatch,
     ScoringAlgorithm,
     SimClustersANNConfig,

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <limits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -289,7 +290,7 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
   *out = nullptr;
   if (!ix) return fail(SANN_EINVAL, "index is NULL");
   if (nq < 0) return fail(SANN_EINVAL, "nq < 0");
-  if (variant < 0 || variant > 2) return fail(SANN_EINVAL, "unknown variant");
+  if (variant < 0 || variant > 3) return fail(SANN_EINVAL, "unknown variant");
   if (nq > 0 && (!emb_offsets || !configs)) return fail(SANN_EINVAL, "emb_offsets/configs are NULL");
   if (n_configs != 1 && n_configs != nq) return fail(SANN_EINVAL, "n_configs must be 1 or nq");
   if ((scan_offsets == nullptr) != (scan_cluster_ids == nullptr) && nq > 0 && scan_offsets &&
@@ -339,6 +340,16 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
     h.l2norm = std::sqrt(sumsq);
     h.lognorm = strict_log(sumsq + 1);
     h.min_score = cfg.min_score;
+    if (variant == SANN_VARIANT_LEGACY) {
+      // SimClustersANNCandidateSource.scala:160-180: the "log" form divides by l2norm, nothing is
+      // filtered by minScore, and there is no cap below maxNumResults
+      if (cfg.ann_algorithm != SANN_ALG_DOT_PRODUCT && cfg.ann_algorithm != SANN_ALG_COSINE &&
+          cfg.ann_algorithm != SANN_ALG_LOG_COSINE)
+        return fail(SANN_EINVAL, "legacy variant: ann_algorithm must be dot product, cosine or log cosine");
+      if (cfg.max_num_results > 1000) return fail(SANN_ELIMIT, "legacy variant: max_num_results above 1000");
+      h.lognorm = h.l2norm;
+      h.min_score = -std::numeric_limits<double>::infinity();
+    }
     h.M = cfg.max_top_tweets_per_cluster < 0 ? 0 : cfg.max_top_tweets_per_cluster;
     int k = cfg.max_num_results < 1000 ? cfg.max_num_results : 1000;
     h.k = k < 0 ? 0 : k;
@@ -346,13 +357,13 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
     kmax = std::max(kmax, h.k);
     h.alg = cfg.ann_algorithm;
     // age window (ApproximateCosineSimilarity.scala:65-72)
-    h.earliest = cfg.max_tweet_candidate_age_hours >= 175200
+    h.earliest = (cfg.max_tweet_candidate_age_hours >= 175200 && variant != SANN_VARIANT_LEGACY)
                      ? 0
                      : snowflake_first_id_for(now_ms - (int64_t)cfg.max_tweet_candidate_age_hours * 3600000ll);
     h.latest = snowflake_first_id_for(now_ms - (int64_t)cfg.min_tweet_candidate_age_hours * 3600000ll);
     // source-tweet exclusion (:90 ; Optimized :56,:67 ; Experimental :59,:70)
     bool has_src = has_source_tweet && has_source_tweet[q] && source_tweet_ids;
-    if (variant == SANN_VARIANT_ORIGINAL) {
+    if (variant == SANN_VARIANT_ORIGINAL || variant == SANN_VARIANT_LEGACY) {
       h.excl_enabled = has_src ? 1 : 0;
       h.src_excl = has_src ? source_tweet_ids[q] : 0;
     } else {

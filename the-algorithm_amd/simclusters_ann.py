@@ -40,6 +40,7 @@ class Variant(enum.IntEnum):
     original = 0
     optimized = 1
     experimental = 2
+    legacy = 3  # simclusters_v2/candidate_source/SimClustersANNCandidateSource.scala:107-181 (not a flag value there)
 
 
 class sann_config_t(C.Structure):
@@ -482,3 +483,65 @@ class ApproximateCosineSimilarity:
             candidateScoresStat(int(msz[q]))
             out.append([(int(ids[q, i]), float(scores[q, i])) for i in range(counts[q])])
         return out
+
+
+@dataclasses.dataclass
+class LegacySimClustersANNConfig:
+    """simclusters_v2/candidate_source/SimClustersANNCandidateSource.scala:214-260 (`SimClustersANNConfig`
+    case class of the legacy in-process source).  Ages in hours; rankingAlgorithm is a
+    representation_scorer.ScoringAlgorithm (score.thrift pair ids)."""
+
+    maxNumResults: int = 200
+    maxTweetCandidateAgeHours: int = 24
+    minTweetCandidateAgeHours: int = 0
+    minScore: float = 0.0
+    candidateEmbeddingType: int = 0
+    enablePartialNormalization: bool = True
+    enableHeavyRanking: bool = False
+    rankingAlgorithm: int = 2  # PairEmbeddingCosineSimilarity
+    maxReRankingCandidates: int = 400
+    maxTopTweetsPerCluster: int = 200
+    maxScanClusters: int = 50
+
+
+class LegacySimClustersANNCandidateSource:
+    """fetchCandidates + reranking of the legacy source (SimClustersANNCandidateSource.scala:107-200) on the
+    device: light ranking through the LEGACY variant of the C ABI, the optional heavy re-rank
+    (HeavyRanker.UniformScoreStoreRanker, HeavyRanker.scala:32-77) through the resident pair scorer.
+    Orders left open by the reference (HashMap / Map iteration under a stable sort) are fixed as
+    everywhere else: score descending, tweet id ascending."""
+
+    LOG_COSINE = 6  # ScoringAlgorithm.PairEmbeddingLogCosineSimilarity
+
+    def __init__(self, index: ClusterTweetIndex, source_store=None, tweet_store=None, now_ms: Optional[int] = None):
+        self.index, self.source_store, self.tweet_store, self.now_ms = index, source_store, tweet_store, now_ms
+
+    def get(self, sourceEmbedding: Iterable[Tuple[int, float]], sourceEmbeddingId: Optional[int], config: LegacySimClustersANNConfig,
+            source_internal_id: Optional[int] = None, now_ms: Optional[int] = None) -> List[Tuple[int, float]]:
+        """sourceEmbeddingId: tweet id when the source is a tweet (parseTweetId), else None.
+        source_internal_id: the id the heavy ranker looks the source embedding up under."""
+        from . import representation_scorer as rs
+
+        if not config.enablePartialNormalization:
+            alg = ScoringAlgorithm.DotProduct
+        elif int(config.rankingAlgorithm) == self.LOG_COSINE:
+            alg = ScoringAlgorithm.LogCosineSimilarity
+        else:
+            alg = ScoringAlgorithm.CosineSimilarity
+        light_k = config.maxReRankingCandidates if config.enableHeavyRanking else config.maxNumResults
+        cfg = SimClustersANNConfig(maxNumResults=light_k, minScore=0.0, candidateEmbeddingType=config.candidateEmbeddingType,
+                                   maxTopTweetsPerCluster=config.maxTopTweetsPerCluster, maxScanClusters=config.maxScanClusters,
+                                   maxTweetCandidateAgeHours=config.maxTweetCandidateAgeHours,
+                                   minTweetCandidateAgeHours=config.minTweetCandidateAgeHours, annAlgorithm=alg)
+        light = ApproximateCosineSimilarity(self.index, Variant.legacy, self.now_ms).apply(
+            sourceEmbedding, sourceEmbeddingId, cfg, now_ms=now_ms)
+        if not config.enableHeavyRanking:
+            return light[:max(config.maxNumResults, 0)]
+        if self.source_store is None or self.tweet_store is None:
+            raise ValueError("heavy ranking needs the source and tweet embedding stores")
+        sid = source_internal_id if source_internal_id is not None else sourceEmbeddingId
+        ids = [t for t, _ in light]
+        scores = rs.list_scores(rs.ScoringAlgorithm(int(config.rankingAlgorithm)), self.source_store, self.tweet_store, sid, ids)
+        ranked = [(t, s) for t, s in zip(ids, scores) if s is not None and s >= config.minScore]
+        ranked.sort(key=lambda x: (-x[1], x[0]))
+        return ranked[:max(config.maxNumResults, 0)]
