@@ -1,0 +1,84 @@
+/*
+ * hnsw_ann.h -- C ABI of the HNSW graph search (ann/hnsw), MI355X.
+ *
+ * Replaces the query side of the reference's Java HNSW (all paths relative to
+ * /root/reference/ann/src/main/):
+ *   java/com/twitter/ann/hnsw/HnswIndex.java:538-553    searchKnn(query, numOfNeighbours, ef)
+ *   java/com/twitter/ann/hnsw/HnswIndex.java:447-475    bestEntryPointUntilLayer (greedy descent)
+ *   java/com/twitter/ann/hnsw/HnswIndex.java:571-623    searchLayerForCandidates (beam search, layer 0)
+ *   java/com/twitter/ann/hnsw/DistancedItemQueue.java   min / max queues = java.util.PriorityQueue ordered by
+ *                                                       Float.compare on the distance (:37-43)
+ *   scala/com/twitter/ann/hnsw/Hnsw.scala:95-147        queryWithDistance: ef from HnswParams, Cosine =
+ *                                                       normalised vectors + InnerProduct (:139-155)
+ *   scala/com/twitter/ann/hnsw/DistanceFunctionGenerator.scala:12-30
+ * The graph is data: `Map<HnswNode(level, item), ImmutableList<item>>` + HnswMeta(maxLevel, entryPoint)
+ * (HnswIndex.java:56-72), what HnswIndexIOUtil reads from an index directory.  hnsw_index_build takes
+ * exactly that, as flat arrays.  hnsw_index_build_insert builds a graph with the reference's insertion
+ * algorithm (HnswIndex.java:137-200,384-440,479-526) on the host, single-threaded and deterministic; the
+ * reference builds offline and any graph it wrote can be loaded instead.
+ *
+ * Search results are a function of (graph, float distances): the walk reproduces the reference step by
+ * step, including java.util.PriorityQueue's sift order, so equal distances are handled as the JVM would.
+ * Distances: vectors and queries rounded to fp16, products and sums in fp32 in a fixed order (8 strided
+ * partial sums of 8-element chunks, then a pairwise tree) that oracle/hnsw_oracle.c repeats bit for bit.
+ * The reference's own fp32 arithmetic (EmbeddingMath, un-vendored) is not pinned by any fixture: parity
+ * with the JVM is "unpinned" in the float distances, exact in the walk given the distances.
+ */
+#ifndef HNSW_ANN_H
+#define HNSW_ANN_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HNSW_OK 0
+#define HNSW_EINVAL 1
+#define HNSW_EDEVICE 2
+#define HNSW_ELIMIT 3
+
+/* ann_common.thrift:16-19 */
+#define HNSW_METRIC_L2 0
+#define HNSW_METRIC_COSINE 1
+#define HNSW_METRIC_INNER_PRODUCT 2
+
+typedef struct hnsw_index hnsw_index_t;
+
+const char *hnsw_last_error(void);
+
+/* Load a graph.  Items are positions 0..n-1 of `vectors` (row-major fp32 [n][d], d <= 512); `ids` (or NULL =
+ * position) are what searches return.  Graph entry e is HnswNode(entry_level[e], entry_item[e]) with
+ * neighbours entry_neighbours[entry_offsets[e] .. entry_offsets[e+1]) in list order.  max_m bounds the
+ * lists: 2*max_m at level 0, max_m above (HnswIndex.java:117).  entry_point < 0 = empty index. */
+int hnsw_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                     int32_t max_m, int64_t entry_point, int32_t max_level, int64_t n_entries, const int32_t *entry_level,
+                     const int64_t *entry_item, const int64_t *entry_offsets, const int64_t *entry_neighbours,
+                     hnsw_index_t **out);
+
+/* Build the graph by inserting items 0..n-1 in order (HnswIndex.insert), then load it.
+ * Level draw: (int)(-ln(U) / ln(max_m)) with U from a 64-bit mixer of (seed, item) (HnswIndex.java:118,369-371). */
+int hnsw_index_build_insert(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                            int32_t max_m, int32_t ef_construction, uint64_t seed, hnsw_index_t **out);
+
+/* The graph back as flat arrays (two calls: sizes, then contents) and the stored (fp16-rounded) vectors. */
+int hnsw_index_graph_size(const hnsw_index_t *index, int64_t *n_entries, int64_t *n_neighbours, int64_t *entry_point,
+                          int32_t *max_level);
+int hnsw_index_graph(const hnsw_index_t *index, int32_t *entry_level, int64_t *entry_item, int64_t *entry_offsets,
+                     int64_t *entry_neighbours);
+int hnsw_index_get_vectors(const hnsw_index_t *index, int64_t i0, int64_t n, float *out);
+int hnsw_index_destroy(hnsw_index_t *index);
+
+/* searchKnn for nq queries (row-major fp32 [nq][d]): out_dist / out_ids [nq][k] ascending by distance,
+ * out_counts[nq] = neighbours found (<= k).  ef as HnswParams.ef; the beam is max(ef, k) (HnswIndex.java:545).
+ * max(ef, k) <= 1024. */
+int hnsw_search(hnsw_index_t *index, int32_t nq, const float *queries, int32_t k, int32_t ef, float *out_dist,
+                int64_t *out_ids, int32_t *out_counts);
+
+/* Work counters of the last hnsw_search: distance evaluations, layer-0 expansions, queries that needed the
+ * global-memory queues, and the kernel time (HIP events, ms). */
+int hnsw_last_stats(const hnsw_index_t *index, int64_t *distance_evals, int64_t *expansions, int32_t *spilled_queries,
+                    float *kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

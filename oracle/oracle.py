@@ -37,7 +37,7 @@ def lib() -> C.CDLL:
     if _lib is None:
         src_newer = (not os.path.exists(LIB)) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(LIB)
-            for f in ("simclusters_oracle.c", "oracle_baseline.c", "Makefile"))
+            for f in ("simclusters_oracle.c", "oracle_baseline.c", "hnsw_oracle.c", "Makefile"))
         if src_newer:
             build()
         L = C.CDLL(LIB)
@@ -218,3 +218,26 @@ def rsx_engagement_features(algorithm, cand, map_ids, map_embeddings, groups):
             mx = max(mx, v)
         out.append((total / len(vals), mx))
     return out
+
+
+
+# ---------------------------------------------------------------------------------------------
+# HNSW walk (oracle/hnsw_oracle.c).  `graph` = (entry_level int32[], entry_item int64[], entry_offsets int64[],
+# entry_neighbours int64[], entry_point, max_level): the reference's Map<HnswNode, List> + HnswMeta, flattened.
+# ---------------------------------------------------------------------------------------------
+def hnsw_search(metric: int, stored: np.ndarray, graph, query: np.ndarray, k: int, ef: int):
+    """searchKnn for one prepared query (dense_prepare) over fp16-rounded stored vectors.
+    Returns (items int64[m], distances float32[m], distance evaluations)."""
+    L = lib()
+    L.oracle_hnsw_search.restype = C.c_int32
+    lv, it, off, nb, entry, max_level = graph
+    x = np.ascontiguousarray(stored, np.float32)
+    q = np.ascontiguousarray(query, np.float32)
+    lv = np.ascontiguousarray(lv, np.int32); it = np.ascontiguousarray(it, np.int64)
+    off = np.ascontiguousarray(off, np.int64); nb = np.ascontiguousarray(nb, np.int64)
+    out_i = np.zeros(k, np.int64); out_d = np.zeros(k, np.float32)
+    evals = C.c_int64()
+    m = L.oracle_hnsw_search(C.c_int32(metric), C.c_int64(x.shape[0]), C.c_int32(x.shape[1]), _p(x), _p(q), C.c_int64(entry),
+                             C.c_int32(max_level), C.c_int64(len(lv)), _p(lv), _p(it), _p(off), _p(nb), C.c_int32(k), C.c_int32(ef),
+                             _p(out_i), _p(out_d), C.byref(evals))
+    return out_i[:m].copy(), out_d[:m].copy(), evals.value

@@ -23,6 +23,11 @@ def test_library_exports_every_declared_symbol(pkg):
     assert declared_rsx == set(pkg.representation_scorer.PROTOS)
     for name in sorted(declared_rsx):
         assert hasattr(lib, name), f"{name} declared in include/representation_scorer.h but not exported"
+    hn = open(os.path.join(ROOT, "include", "hnsw_ann.h")).read()
+    declared_hn = set(re.findall(r"\b(hnsw_[a-z_0-9]+)\s*\(", hn))
+    assert declared_hn == set(pkg.hnsw_ann.PROTOS)
+    for name in sorted(declared_hn):
+        assert hasattr(lib, name), f"{name} declared in include/hnsw_ann.h but not exported"
     dann = open(os.path.join(ROOT, "include", "dense_ann.h")).read()
     declared_dann = set(re.findall(r"\b(dann_[a-z_0-9]+)\s*\(", dann))
     assert declared_dann == set(pkg.dense_ann.PROTOS)
@@ -44,6 +49,9 @@ def test_version_and_error_paths(pkg):
     rl = pkg.representation_scorer._lib()
     assert rl.rsx_store_pair_scores(None, None, 2, 1, None, None, None, None) == 1  # RSX_EINVAL before any HIP call
     assert rl.rsx_store_destroy(None) == 0
+    hl = pkg.hnsw_ann._lib()
+    assert hl.hnsw_search(None, 1, None, 1, 1, None, None, None) == 1  # HNSW_EINVAL before any HIP call
+    assert hl.hnsw_index_destroy(None) == 0
     dl = pkg.dense_ann._lib()
     assert dl.dann_index_build(0, 0, 10, 16, None, None, C.byref(h)) == 1  # DANN_EINVAL before any HIP call
     assert dl.dann_search(None, 1, None, 1, None, None, None) == 1

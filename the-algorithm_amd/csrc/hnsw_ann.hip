@@ -1,0 +1,1003 @@
+// hnsw_ann.hip -- HNSW graph search on gfx950 (include/hnsw_ann.h) + the host-side graph builder.
+//
+// Reference (paths relative to /root/reference/ann/src/main/java/com/twitter/ann/hnsw/):
+//   HnswIndex.java:538-553   searchKnn            HnswIndex.java:447-475  bestEntryPointUntilLayer
+//   HnswIndex.java:571-623   searchLayerForCandidates
+//   HnswIndex.java:137-200,384-440,479-526  insert / mutuallyConnectNewElement / selectNearestNeighboursByHeuristic
+//   DistancedItemQueue.java:37-43           queues = java.util.PriorityQueue on Float.compare(distance)
+//
+// The walk is inherently sequential -- which neighbour is admitted depends on the queue state the
+// previous one left -- so the GPU does not parallelise the walk of one query; it runs ~1500 of them
+// at once (one wave per query, six waves per CU) and inside a step parallelises what IS parallel:
+//   * visited test-and-set for a whole neighbour list: one atomicOr per lane on a per-query bitmap;
+//   * distances of the unvisited neighbours: 8 lanes per vector (16-B loads, 128 B contiguous per
+//     group), 8 vectors per round, all rounds' loads issued before the first reduction;
+//   * then the reference's own admission loop, in list order, on the two queues.
+// The queues are java.util.PriorityQueue restated (same siftUp / siftDown), held in LDS, operated
+// wave-uniformly; that makes equal distances come out as on the JVM.  A query whose candidate queue
+// outgrows LDS is re-run with both queues in global memory (same code, GLOBALQ = true).
+// HBM-latency bound by nature: every expansion is a dependent gather of <= 2*maxM random 512-B rows.
+//
+// Distance arithmetic (the fixed order oracle/hnsw_oracle.c repeats): operands rounded to fp16, fp32
+// products and sums, lane j of 8 sums chunks j, j+8, ... of 8 consecutive elements, then a pairwise
+// butterfly (xor 1, 2, 4).  Compiled with -ffp-contract=off, so host (builder) == device == oracle.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/hnsw_ann.h"
+#include "sann_device.h"  // mix64
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &m) {
+  g_err = m;
+  return code;
+}
+#define HTRY(expr)                                                                                 \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(HNSW_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+constexpr int MAX_D = 512;
+constexpr int MAX_M = 32;        // lists of <= 2*MAX_M = 64 neighbours: one lane each
+constexpr int MAX_EF = 1024;
+constexpr int CCAP_LDS = 2048;   // candidate queue entries in LDS
+constexpr int CCAP_GLOBAL = 1 << 17;
+
+struct Buf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~Buf() { if (p) (void)hipFree(p); }
+  hipError_t reserve(size_t n) {
+    if (n <= bytes && p) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, n ? n : 8);
+    if (e == hipSuccess) bytes = n ? n : 8;
+    return e;
+  }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// shared host/device pieces: Float.compare and java.util.PriorityQueue
+// ---------------------------------------------------------------------------------------------
+struct HEntry {
+  float dist;
+  uint32_t node;
+};
+
+__host__ __device__ inline int32_t float_to_int_bits(float f) {  // Float.floatToIntBits: canonical NaN
+  if (f != f) return 0x7fc00000;
+#ifdef __HIP_DEVICE_COMPILE__
+  return __float_as_int(f);
+#else
+  int32_t i;
+  std::memcpy(&i, &f, 4);
+  return i;
+#endif
+}
+__host__ __device__ inline int float_compare(float a, float b) {  // java.lang.Float.compare
+  if (a < b) return -1;
+  if (a > b) return 1;
+  const int32_t x = float_to_int_bits(a), y = float_to_int_bits(b);
+  return x == y ? 0 : (x < y ? -1 : 1);
+}
+// comparator of a DistancedItemQueue (DistancedItemQueue.java:37-43)
+template <bool MINQ>
+__host__ __device__ inline int qcmp(const HEntry &a, const HEntry &b) {
+  return MINQ ? float_compare(a.dist, b.dist) : float_compare(b.dist, a.dist);
+}
+// PriorityQueue.offer -> siftUpUsingComparator
+template <bool MINQ>
+__host__ __device__ inline void pq_add(HEntry *q, int &n, HEntry x) {
+  int k = n++;
+  while (k > 0) {
+    const int parent = (k - 1) >> 1;
+    const HEntry e = q[parent];
+    if (qcmp<MINQ>(x, e) >= 0) break;
+    q[k] = e;
+    k = parent;
+  }
+  q[k] = x;
+}
+// PriorityQueue.poll -> siftDownUsingComparator
+template <bool MINQ>
+__host__ __device__ inline HEntry pq_poll(HEntry *q, int &n) {
+  const HEntry result = q[0];
+  const int s = --n;
+  if (s > 0) {
+    const HEntry x = q[s];
+    int k = 0;
+    const int half = s >> 1;
+    while (k < half) {
+      int child = 2 * k + 1;
+      HEntry c = q[child];
+      const int right = child + 1;
+      if (right < s) {
+        const HEntry r = q[right];
+        if (qcmp<MINQ>(c, r) > 0) {
+          c = r;
+          child = right;
+        }
+      }
+      if (qcmp<MINQ>(x, c) <= 0) break;
+      q[k] = c;
+      k = child;
+    }
+    q[k] = x;
+  }
+  return result;
+}
+
+// distance from the fixed-order sum (see file header)
+__host__ __device__ inline float finish_distance(int metric, float s) {
+  return metric == HNSW_METRIC_L2 ? sqrtf(s) : 1.0f - s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+struct SearchArgs {
+  const _Float16 *x;          // [n][dpad]
+  const _Float16 *q;          // [nq][dpad] prepared queries
+  const uint32_t *adj0;       // [n][m0 + 1]: count, neighbours
+  const int32_t *upper_slot;  // [n]: row group of a node with levels >= 1, or -1
+  const int32_t *upper_base;  // [n_upper + 1]: first row of the slot; rows = levels 1..top
+  const uint32_t *upper_adj;  // [rows][m + 1]
+  const int64_t *ids;         // or NULL
+  const int32_t *qlist;       // queries of this launch (spill re-run) or NULL = blockIdx
+  uint32_t *visited;          // [slots][vwords]
+  HEntry *gc, *gw;            // global queues (GLOBALQ): [slots][CCAP_GLOBAL], [slots][MAX_EF + 1]
+  float *out_dist;            // [nq][k]
+  int64_t *out_ids;
+  int32_t *out_counts;
+  int32_t *spill;             // [nq] set when the LDS candidate queue overflowed
+  unsigned long long *stats;  // [0] distance evaluations, [1] expansions
+  int64_t vwords;
+  int32_t dpad, chunks, m, m0, metric, k, ef, max_level;
+  int32_t ccap_lds;           // candidate-queue entries allowed in LDS (<= CCAP_LDS; smaller only for tests)
+  uint32_t entry;
+};
+
+// distances of nu nodes (ids in nodes[], LDS) to the wave's query; results to dists[] (LDS)
+template <int CH>  // chunks of 8 halves per lane: dpad / 64
+__device__ __forceinline__ void wave_distances(const SearchArgs &a, const float (&qv)[CH][8], const uint32_t *nodes,
+                                               float *dists, int nu, int lane) {
+  const int g = lane >> 3, j = lane & 7;
+  for (int base = 0; base < nu; base += 32) {  // up to 4 rounds of 8 vectors in flight
+    half8 xv[4][CH];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = base + r * 8 + g;
+      if (idx < nu) {
+        const half8 *row = (const half8 *)(a.x + (size_t)nodes[idx] * a.dpad);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) xv[r][c] = row[j + 8 * c];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = base + r * 8 + g;
+      float acc = 0.0f;
+      if (idx < nu) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xe = (float)xv[r][c][e];
+            if (a.metric == HNSW_METRIC_L2) {
+              const float t = qv[c][e] - xe;
+              acc = acc + t * t;
+            } else {
+              acc = acc + qv[c][e] * xe;
+            }
+          }
+      }
+      acc = acc + __shfl_xor(acc, 1, 64);
+      acc = acc + __shfl_xor(acc, 2, 64);
+      acc = acc + __shfl_xor(acc, 4, 64);
+      if (idx < nu && j == 0) dists[idx] = finish_distance(a.metric, acc);
+    }
+  }
+}
+
+template <int CH, bool GLOBALQ>
+__global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
+  __shared__ HEntry cq_s[GLOBALQ ? 1 : CCAP_LDS];
+  __shared__ HEntry wq_s[GLOBALQ ? 1 : MAX_EF + 1];
+  __shared__ uint32_t ul[64];
+  __shared__ float ud[64];
+  const int lane = threadIdx.x;
+  const int slot = blockIdx.x;
+  const int qi = a.qlist ? a.qlist[slot] : slot;
+  HEntry *cq = GLOBALQ ? a.gc + (size_t)slot * CCAP_GLOBAL : cq_s;
+  HEntry *wq = GLOBALQ ? a.gw + (size_t)slot * (MAX_EF + 1) : wq_s;
+  const int ccap = GLOBALQ ? CCAP_GLOBAL : a.ccap_lds;
+  uint32_t *vis = a.visited + (size_t)slot * a.vwords;
+
+  float qv[CH][8];
+  {
+    const half8 *qrow = (const half8 *)(a.q + (size_t)qi * a.dpad);
+    const int j = lane & 7;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const half8 v = qrow[j + 8 * c];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[c][e] = (float)v[e];
+    }
+  }
+  unsigned long long n_dist = 0, n_exp = 0;
+
+  // ---- bestEntryPointUntilLayer (HnswIndex.java:447-475) ----
+  uint32_t cur = a.entry;
+  if (a.max_level > 0) {
+    if (lane == 0) ul[0] = cur;
+    __syncthreads();
+    wave_distances<CH>(a, qv, ul, ud, 1, lane);
+    __syncthreads();
+    float cur_dist = ud[0];
+    n_dist += 1;
+    for (int level = a.max_level; level > 0; --level) {
+      bool changed = true;
+      while (changed) {
+        changed = false;
+        int cnt = 0;
+        const int us = a.upper_slot[cur];
+        if (us >= 0) {
+          const int rows = a.upper_base[us + 1] - a.upper_base[us];
+          if (level <= rows) {
+            const uint32_t *row = a.upper_adj + (size_t)(a.upper_base[us] + level - 1) * (a.m + 1);
+            cnt = (int)row[0];
+            if (lane < cnt) ul[lane] = row[1 + lane];
+          }
+        }
+        __syncthreads();
+        if (cnt > 0) {
+          wave_distances<CH>(a, qv, ul, ud, cnt, lane);
+          __syncthreads();
+          n_dist += cnt;
+          // `for nn in list: if (d < curDist) take it`: the running strict minimum, in list order
+          for (int i = 0; i < cnt; ++i) {
+            const float t = ud[i];
+            if (t < cur_dist) {
+              cur_dist = t;
+              cur = ul[i];
+              changed = true;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- searchLayerForCandidates(query, entryPoint, max(ef, k), 0) (HnswIndex.java:571-623) ----
+  const int ef = a.ef;
+  if (lane == 0) ul[0] = cur;
+  __syncthreads();
+  wave_distances<CH>(a, qv, ul, ud, 1, lane);
+  __syncthreads();
+  n_dist += 1;
+  int cn = 0, wn = 0;
+  bool overflow = false;
+  {
+    const HEntry e0{ud[0], cur};
+    pq_add<true>(cq, cn, e0);
+    pq_add<false>(wq, wn, e0);
+    if (lane == 0) atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+  }
+  float lower = wq[0].dist;
+  __syncthreads();
+  while (cn > 0) {
+    const HEntry cand = cq[0];
+    if (cand.dist > lower) break;
+    (void)pq_poll<true>(cq, cn);
+    n_exp += 1;
+    const uint32_t *row = a.adj0 + (size_t)cand.node * (a.m0 + 1);
+    const int cnt = (int)row[0];
+    uint32_t nn = 0;
+    bool fresh = false;
+    if (lane < cnt) {
+      nn = row[1 + lane];
+      const uint32_t bit = 1u << (nn & 31);
+      fresh = (atomicOr(&vis[nn >> 5], bit) & bit) == 0;  // visited.contains / visited.add
+    }
+    const unsigned long long mask = __ballot(fresh);
+    const int nu = __popcll(mask);
+    if (fresh) ul[__popcll(mask & ((1ull << lane) - 1))] = nn;  // list order is kept
+    __syncthreads();
+    if (nu > 0) {
+      wave_distances<CH>(a, qv, ul, ud, nu, lane);
+      __syncthreads();
+      n_dist += nu;
+      for (int i = 0; i < nu; ++i) {
+        const HEntry e{ud[i], ul[i]};
+        if (wn < ef || e.dist < wq[0].dist) {
+          if (cn >= ccap) {
+            overflow = true;
+            break;
+          }
+          pq_add<true>(cq, cn, e);
+          pq_add<false>(wq, wn, e);
+          if (wn > ef) (void)pq_poll<false>(wq, wn);
+          lower = wq[0].dist;
+        }
+      }
+    }
+    __syncthreads();
+    if (overflow) break;
+  }
+  if (lane == 0) {
+    atomicAdd(&a.stats[0], n_dist);
+    atomicAdd(&a.stats[1], n_exp);
+  }
+  if (overflow) {
+    if (lane == 0) a.spill[qi] = 1;
+    return;
+  }
+  // dequeueAll (descending), reverse, first k (HnswIndex.java:546-549)
+  const int found = wn;
+  const int m = found < a.k ? found : a.k;
+  for (int pos = found - 1; pos >= 0; --pos) {
+    const HEntry e = pq_poll<false>(wq, wn);
+    if (pos < m && lane == 0) {
+      a.out_dist[(size_t)qi * a.k + pos] = e.dist;
+      a.out_ids[(size_t)qi * a.k + pos] = a.ids ? a.ids[e.node] : (int64_t)e.node;
+    }
+  }
+  if (lane == 0) {
+    a.out_counts[qi] = m;
+    a.spill[qi] = 0;
+  }
+}
+
+// rows (fp32) -> fp16 rows padded to dpad; Cosine rows are normalised first (Hnsw.scala:149-155)
+__global__ void hnsw_prep_rows(const float *__restrict__ src, int64_t n, int d, int dpad, int normalise,
+                               _Float16 *__restrict__ dst) {
+  int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float *x = src + row * d;
+  float norm = 1.0f;
+  if (normalise) {
+    double ss = 0;
+    for (int k = lane; k < d; k += 64) ss += (double)x[k] * (double)x[k];
+    for (int o = 32; o; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    norm = (float)sqrt(ss);
+    if (!(norm > 0.0f)) norm = 1.0f;
+  }
+  for (int k = lane; k < dpad; k += 64) dst[row * dpad + k] = (_Float16)(k < d ? x[k] / norm : 0.0f);
+}
+
+__global__ void hnsw_rows_to_f32(const _Float16 *__restrict__ src, int64_t i0, int64_t n, int d, int dpad,
+                                 float *__restrict__ dst) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * d) return;
+  dst[e] = (float)src[(i0 + e / d) * dpad + e % d];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host: the index, the reference's insertion algorithm, the C ABI
+// ---------------------------------------------------------------------------------------------
+struct hnsw_index {
+  int device = 0, metric = 0, d = 0, dpad = 0, m = 0, m0 = 0, max_level = 0;
+  int64_t n = 0, entry = -1;
+  std::vector<std::vector<std::vector<uint32_t>>> upper;  // [level - 1][slot] lists, host copy for export
+  std::vector<std::vector<uint32_t>> level0;              // host copy
+  std::vector<uint8_t> has0;                              // node has a level-0 entry
+  std::vector<int32_t> upper_slot_h, upper_base_h;
+  std::vector<std::vector<uint8_t>> has_upper;            // [slot][level - 1]: entry exists
+  Buf x, adj0, upper_slot, upper_base, upper_adj, ids;
+  bool has_ids = false;
+  // scratch
+  Buf q_in, q, visited, gc, gw, o_dist, o_ids, o_cnt, spill, stats, qlist;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int64_t last_dist = 0, last_exp = 0;
+  int32_t last_spilled = 0;
+  float last_ms = 0;
+  ~hnsw_index() {
+    for (auto &e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+};
+
+namespace {
+
+// graph under construction / being loaded: lists[level][item]
+struct HostGraph {
+  int64_t n = 0;
+  int m = 0, m0 = 0;
+  int max_level = -1;  // HnswIndex.java:97
+  int64_t entry = -1;
+  std::vector<std::vector<uint32_t>> l0;  // [n]
+  std::vector<uint8_t> has0;
+  std::vector<std::unordered_map<uint32_t, std::vector<uint32_t>>> up;  // [level - 1]
+  const std::vector<uint32_t> *get(int level, uint32_t item) const {  // getConnectionListForRead
+    if (level == 0) return has0[item] ? &l0[item] : nullptr;
+    if (level - 1 >= (int)up.size()) return nullptr;
+    auto it = up[(size_t)level - 1].find(item);
+    return it == up[(size_t)level - 1].end() ? nullptr : &it->second;
+  }
+  void put(int level, uint32_t item, std::vector<uint32_t> list) {
+    if (level == 0) {
+      l0[item] = std::move(list);
+      has0[item] = 1;
+    } else {
+      if ((int)up.size() < level) up.resize((size_t)level);
+      up[(size_t)level - 1][item] = std::move(list);
+    }
+  }
+};
+
+struct HostVectors {
+  const float *x;  // fp16-rounded, [n][dpad]
+  int dpad, metric;
+  float distance(uint32_t a, uint32_t b) const { return distance(x + (size_t)a * dpad, b); }
+  float distance(const float *q, uint32_t b) const {
+    const float *y = x + (size_t)b * dpad;
+    float p[8];
+    for (int j = 0; j < 8; ++j) {
+      float acc = 0.0f;
+      for (int c = j; c < dpad / 8; c += 8)
+        for (int e = 0; e < 8; ++e) {
+          if (metric == HNSW_METRIC_L2) {
+            const float t = q[c * 8 + e] - y[c * 8 + e];
+            acc = acc + t * t;
+          } else {
+            acc = acc + q[c * 8 + e] * y[c * 8 + e];
+          }
+        }
+      p[j] = acc;
+    }
+    const float r0 = p[0] + p[1], r2 = p[2] + p[3], r4 = p[4] + p[5], r6 = p[6] + p[7];
+    return finish_distance(metric, (r0 + r2) + (r4 + r6));
+  }
+};
+
+// DistancedItemQueue on the host
+struct JQueue {
+  std::vector<HEntry> q;
+  int n = 0;
+  bool minq;
+  uint32_t origin;
+  explicit JQueue(bool mq, uint32_t o) : minq(mq), origin(o) {}
+  void add(HEntry e) {
+    if ((int)q.size() <= n) q.resize((size_t)n + 64);
+    if (minq) pq_add<true>(q.data(), n, e);
+    else pq_add<false>(q.data(), n, e);
+  }
+  HEntry poll() { return minq ? pq_poll<true>(q.data(), n) : pq_poll<false>(q.data(), n); }
+  JQueue reverse() const {  // DistancedItemQueue.reverse: re-add in array (iterator) order
+    JQueue r(!minq, origin);
+    for (int i = 0; i < n; ++i) r.add(q[(size_t)i]);
+    return r;
+  }
+};
+
+struct Builder {
+  HostGraph &g;
+  const HostVectors &v;
+  int ef_construction;
+  std::vector<uint32_t> stamp;  // visited set, epoch-stamped
+  uint32_t epoch = 0;
+
+  uint32_t best_entry(uint32_t entry, uint32_t item, int max_layer, int selected) {  // HnswIndex.java:447-475
+    uint32_t cur = entry;
+    if (selected < max_layer) {
+      float cur_dist = v.distance(item, cur);
+      for (int level = max_layer; level > selected; --level) {
+        bool changed = true;
+        while (changed) {
+          changed = false;
+          const std::vector<uint32_t> *list = g.get(level, cur);
+          if (!list) continue;
+          const std::vector<uint32_t> snapshot = *list;
+          for (uint32_t nn : snapshot) {
+            const float t = v.distance(item, nn);
+            if (t < cur_dist) {
+              cur_dist = t;
+              cur = nn;
+              changed = true;
+            }
+          }
+        }
+      }
+    }
+    return cur;
+  }
+
+  JQueue search_layer(uint32_t item, uint32_t entry, int ef, int level) {  // HnswIndex.java:571-623, isUpdate = false
+    JQueue cq(true, item);
+    cq.add(HEntry{v.distance(item, entry), entry});
+    JQueue wq = cq.reverse();
+    ++epoch;
+    stamp[entry] = epoch;
+    float lower = wq.q[0].dist;
+    while (cq.n > 0) {
+      const HEntry cand = cq.q[0];
+      if (cand.dist > lower) break;
+      cq.poll();
+      const std::vector<uint32_t> *list = g.get(level, cand.node);
+      if (!list) continue;
+      for (uint32_t nn : *list) {
+        if (stamp[nn] == epoch) continue;
+        stamp[nn] = epoch;
+        const float dist = v.distance(item, nn);
+        if (wq.n < ef || dist < wq.q[0].dist) {
+          cq.add(HEntry{dist, nn});
+          wq.add(HEntry{dist, nn});
+          if (wq.n > ef) wq.poll();
+          lower = wq.q[0].dist;
+        }
+      }
+    }
+    return wq;
+  }
+
+  std::vector<uint32_t> select(const JQueue &cands, int max_conn) {  // HnswIndex.java:479-526
+    const uint32_t base = cands.origin;
+    std::vector<uint32_t> res;
+    if (cands.n <= max_conn) {
+      bool removed = false;  // List.remove(Object): first occurrence only
+      for (int i = 0; i < cands.n; ++i) {
+        if (!removed && cands.q[(size_t)i].node == base) {
+          removed = true;
+          continue;
+        }
+        res.push_back(cands.q[(size_t)i].node);
+      }
+      return res;
+    }
+    JQueue minq = cands.reverse();
+    while (minq.n > 0) {
+      if ((int)res.size() >= max_conn) break;
+      const HEntry c = minq.poll();
+      if (c.node == base) continue;
+      bool include = true;
+      for (uint32_t e : res) {
+        if (v.distance(e, c.node) < c.dist) {
+          include = false;
+          break;
+        }
+      }
+      if (include) res.push_back(c.node);
+    }
+    return res;
+  }
+
+  uint32_t connect(uint32_t item, const JQueue &cands, int level) {  // mutuallyConnectNewElement, isUpdate = false
+    const std::vector<uint32_t> neighbours = select(cands, g.m);
+    g.put(level, item, neighbours);
+    const int M = level == 0 ? g.m0 : g.m;
+    for (uint32_t nn : neighbours) {
+      if (nn == item) continue;
+      const std::vector<uint32_t> *cur = g.get(level, nn);
+      std::vector<uint32_t> conn = cur ? *cur : std::vector<uint32_t>();
+      if ((int)conn.size() < M) {
+        conn.push_back(item);
+      } else {
+        JQueue q(false, nn);
+        for (uint32_t t : conn) q.add(HEntry{v.distance(nn, t), t});
+        q.add(HEntry{v.distance(nn, item), item});
+        conn = select(q, M);
+      }
+      g.put(level, nn, std::move(conn));
+    }
+    return neighbours.empty() ? item : neighbours[0];
+  }
+
+  void insert(uint32_t item, int cur_level) {  // HnswIndex.java:137-200
+    if (g.entry >= 0) {
+      uint32_t cur = (uint32_t)g.entry;
+      const int max_layer = g.max_level;
+      if (cur_level < max_layer) cur = best_entry(cur, item, max_layer, cur_level);
+      for (int level = std::min(cur_level, max_layer); level >= 0; --level) {
+        const JQueue cands = search_layer(item, cur, ef_construction, level);
+        cur = connect(item, cands, level);
+      }
+    }
+    if (cur_level > g.max_level) {  // HnswMeta starts at (-1, empty): the first item always takes this branch
+      g.max_level = cur_level;
+      g.entry = item;
+    }
+  }
+};
+
+int upload_graph(hnsw_index *ix, const HostGraph &g) {
+  const int64_t n = ix->n;
+  ix->entry = g.entry;
+  ix->max_level = std::max(g.max_level, 0);
+  ix->level0 = g.l0;
+  ix->has0 = g.has0;
+  std::vector<uint32_t> adj0((size_t)n * (ix->m0 + 1), 0);
+  for (int64_t i = 0; i < n; ++i) {
+    const auto &l = g.l0[(size_t)i];
+    adj0[(size_t)i * (ix->m0 + 1)] = (uint32_t)l.size();
+    std::copy(l.begin(), l.end(), adj0.begin() + (size_t)i * (ix->m0 + 1) + 1);
+  }
+  // upper levels: slot per node that has an entry above level 0, rows = its top level
+  std::vector<int32_t> top((size_t)n, 0);
+  for (size_t l = 0; l < g.up.size(); ++l)
+    for (const auto &kv : g.up[l]) top[kv.first] = std::max(top[kv.first], (int32_t)l + 1);
+  ix->upper_slot_h.assign((size_t)n, -1);
+  ix->upper_base_h.assign(1, 0);
+  for (int64_t i = 0; i < n; ++i)
+    if (top[(size_t)i] > 0) {
+      ix->upper_slot_h[(size_t)i] = (int32_t)ix->upper_base_h.size() - 1;
+      ix->upper_base_h.push_back(ix->upper_base_h.back() + top[(size_t)i]);
+    }
+  const int64_t rows = ix->upper_base_h.back();
+  std::vector<uint32_t> uadj((size_t)std::max<int64_t>(rows, 1) * (ix->m + 1), 0);
+  ix->upper.assign(g.up.size(), {});
+  const size_t n_slots = ix->upper_base_h.size() - 1;
+  ix->has_upper.assign(n_slots, {});
+  for (size_t s = 0; s < n_slots; ++s) ix->has_upper[s].assign((size_t)(ix->upper_base_h[s + 1] - ix->upper_base_h[s]), 0);
+  for (size_t l = 0; l < g.up.size(); ++l) {
+    ix->upper[l].assign(n_slots, {});
+    for (const auto &kv : g.up[l]) {
+      const int32_t s = ix->upper_slot_h[kv.first];
+      ix->upper[l][(size_t)s] = kv.second;
+      ix->has_upper[(size_t)s][l] = 1;
+      uint32_t *row = uadj.data() + (size_t)(ix->upper_base_h[(size_t)s] + (int32_t)l) * (ix->m + 1);
+      row[0] = (uint32_t)kv.second.size();
+      std::copy(kv.second.begin(), kv.second.end(), row + 1);
+    }
+  }
+  HTRY(ix->adj0.reserve(adj0.size() * 4));
+  HTRY(hipMemcpy(ix->adj0.p, adj0.data(), adj0.size() * 4, hipMemcpyHostToDevice));
+  HTRY(ix->upper_slot.reserve((size_t)n * 4));
+  HTRY(hipMemcpy(ix->upper_slot.p, ix->upper_slot_h.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  HTRY(ix->upper_base.reserve(ix->upper_base_h.size() * 4));
+  HTRY(hipMemcpy(ix->upper_base.p, ix->upper_base_h.data(), ix->upper_base_h.size() * 4, hipMemcpyHostToDevice));
+  HTRY(ix->upper_adj.reserve(uadj.size() * 4));
+  HTRY(hipMemcpy(ix->upper_adj.p, uadj.data(), uadj.size() * 4, hipMemcpyHostToDevice));
+  return HNSW_OK;
+}
+
+int create_index(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids, int32_t max_m,
+                 std::unique_ptr<hnsw_index> &ix, std::vector<float> *host_rows) {
+  if (metric < HNSW_METRIC_L2 || metric > HNSW_METRIC_INNER_PRODUCT) return fail(HNSW_EINVAL, "unknown metric");
+  if (n < 0 || n >= (int64_t)0x7fffffff) return fail(HNSW_EINVAL, "vector count out of range");
+  if (d < 1 || d > MAX_D) return fail(HNSW_EINVAL, "dimension must be in 1..512");
+  if (max_m < 2 || max_m > MAX_M) return fail(HNSW_EINVAL, "max_m must be in 2..32");
+  if (n > 0 && !vectors) return fail(HNSW_EINVAL, "NULL vectors");
+  ix.reset(new hnsw_index);
+  ix->device = device;
+  ix->metric = metric;
+  ix->n = n;
+  ix->d = d;
+  ix->dpad = (d + 63) / 64 * 64;
+  ix->m = max_m;
+  ix->m0 = 2 * max_m;
+  HTRY(hipSetDevice(device));
+  for (auto &e : ix->ev) HTRY(hipEventCreate(&e));
+  HTRY(ix->x.reserve((size_t)std::max<int64_t>(n, 1) * ix->dpad * sizeof(_Float16)));
+  if (n > 0) {
+    Buf stage;
+    const int64_t chunk = std::max<int64_t>(1, (int64_t)(128u << 20) / ((int64_t)d * 4));
+    HTRY(stage.reserve((size_t)std::min(chunk, n) * d * 4));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+      const int64_t m = std::min(chunk, n - r0);
+      HTRY(hipMemcpy(stage.p, vectors + r0 * d, (size_t)m * d * 4, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(hnsw_prep_rows, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, 0, stage.as<float>(), m, d, ix->dpad,
+                         metric == HNSW_METRIC_COSINE ? 1 : 0, ix->x.as<_Float16>() + r0 * ix->dpad);
+      HTRY(hipGetLastError());
+      HTRY(hipDeviceSynchronize());
+    }
+  }
+  if (ids && n > 0) {
+    HTRY(ix->ids.reserve((size_t)n * 8));
+    HTRY(hipMemcpy(ix->ids.p, ids, (size_t)n * 8, hipMemcpyHostToDevice));
+    ix->has_ids = true;
+  }
+  if (host_rows) {  // the stored rows, as floats, for the host-side builder
+    std::vector<_Float16> h((size_t)n * ix->dpad);
+    if (n > 0) HTRY(hipMemcpy(h.data(), ix->x.p, h.size() * sizeof(_Float16), hipMemcpyDeviceToHost));
+    host_rows->resize(h.size());
+    for (size_t i = 0; i < h.size(); ++i) (*host_rows)[i] = (float)h[i];
+  }
+  return HNSW_OK;
+}
+
+template <int CH>
+void launch_search(bool globalq, int blocks, const SearchArgs &a, hipStream_t st) {
+  if (globalq) hipLaunchKernelGGL((hnsw_search_kernel<CH, true>), dim3(blocks), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL((hnsw_search_kernel<CH, false>), dim3(blocks), dim3(64), 0, st, a);
+}
+void launch_search_any(int chunks, bool globalq, int blocks, const SearchArgs &a, hipStream_t st) {
+  switch (chunks) {
+    case 1: launch_search<1>(globalq, blocks, a, st); break;
+    case 2: launch_search<2>(globalq, blocks, a, st); break;
+    case 3: launch_search<3>(globalq, blocks, a, st); break;
+    case 4: launch_search<4>(globalq, blocks, a, st); break;
+    case 5: launch_search<5>(globalq, blocks, a, st); break;
+    case 6: launch_search<6>(globalq, blocks, a, st); break;
+    case 7: launch_search<7>(globalq, blocks, a, st); break;
+    default: launch_search<8>(globalq, blocks, a, st); break;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hnsw_last_error(void) { return g_err.c_str(); }
+
+int hnsw_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                     int32_t max_m, int64_t entry_point, int32_t max_level, int64_t n_entries, const int32_t *entry_level,
+                     const int64_t *entry_item, const int64_t *entry_offsets, const int64_t *entry_neighbours,
+                     hnsw_index_t **out) {
+  if (!out) return fail(HNSW_EINVAL, "out is NULL");
+  if (n_entries < 0 || (n_entries > 0 && (!entry_level || !entry_item || !entry_offsets)))
+    return fail(HNSW_EINVAL, "NULL graph arrays");
+  if (entry_point >= n || max_level < 0 || max_level > 64) return fail(HNSW_EINVAL, "entry point / max level out of range");
+  std::unique_ptr<hnsw_index> ix;
+  int rc = create_index(device, metric, n, d, vectors, ids, max_m, ix, nullptr);
+  if (rc) return rc;
+  HostGraph g;
+  g.n = n;
+  g.m = max_m;
+  g.m0 = 2 * max_m;
+  g.l0.assign((size_t)n, {});
+  g.has0.assign((size_t)n, 0);
+  g.entry = entry_point < 0 ? -1 : entry_point;
+  g.max_level = max_level;
+  for (int64_t e = 0; e < n_entries; ++e) {
+    const int level = entry_level[e];
+    const int64_t item = entry_item[e];
+    if (level < 0 || level > max_level || item < 0 || item >= n) return fail(HNSW_EINVAL, "graph entry out of range");
+    const int64_t b = entry_offsets[e], en = entry_offsets[e + 1];
+    if (en < b || en - b > (level == 0 ? g.m0 : g.m)) return fail(HNSW_EINVAL, "neighbour list longer than the level allows");
+    std::vector<uint32_t> list;
+    for (int64_t j = b; j < en; ++j) {
+      if (!entry_neighbours || entry_neighbours[j] < 0 || entry_neighbours[j] >= n) return fail(HNSW_EINVAL, "neighbour out of range");
+      list.push_back((uint32_t)entry_neighbours[j]);
+    }
+    g.put(level, (uint32_t)item, std::move(list));
+  }
+  rc = upload_graph(ix.get(), g);
+  if (rc) return rc;
+  *out = ix.release();
+  return HNSW_OK;
+}
+
+int hnsw_index_build_insert(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                            int32_t max_m, int32_t ef_construction, uint64_t seed, hnsw_index_t **out) {
+  if (!out) return fail(HNSW_EINVAL, "out is NULL");
+  if (ef_construction < 1) return fail(HNSW_EINVAL, "ef_construction must be positive");
+  std::unique_ptr<hnsw_index> ix;
+  std::vector<float> rows;
+  int rc = create_index(device, metric, n, d, vectors, ids, max_m, ix, &rows);
+  if (rc) return rc;
+  HostGraph g;
+  g.n = n;
+  g.m = max_m;
+  g.m0 = 2 * max_m;
+  g.l0.assign((size_t)n, {});
+  g.has0.assign((size_t)n, 0);
+  HostVectors hv{rows.data(), ix->dpad, metric};
+  Builder b{g, hv, ef_construction, std::vector<uint32_t>((size_t)n, 0), 0};
+  const double level_mult = 1.0 / std::log(1.0 * max_m);  // HnswIndex.java:118
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t h = sann::mix64(seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull));
+    const double u = ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740992.0);  // (0, 1]
+    int level = (int)(-std::log(u) * level_mult);                             // getRandomLevel, :369-371
+    if (level > 60) level = 60;
+    b.insert((uint32_t)i, level);
+  }
+  rc = upload_graph(ix.get(), g);
+  if (rc) return rc;
+  *out = ix.release();
+  return HNSW_OK;
+}
+
+int hnsw_index_graph_size(const hnsw_index_t *ix, int64_t *n_entries, int64_t *n_neighbours, int64_t *entry_point,
+                          int32_t *max_level) {
+  if (!ix) return fail(HNSW_EINVAL, "NULL index");
+  int64_t ne = 0, nn = 0;
+  for (int64_t i = 0; i < ix->n; ++i)
+    if (ix->has0[(size_t)i]) {
+      ne++;
+      nn += (int64_t)ix->level0[(size_t)i].size();
+    }
+  for (size_t l = 0; l < ix->upper.size(); ++l)
+    for (size_t s = 0; s < ix->upper[l].size(); ++s)
+      if (l < ix->has_upper[s].size() && ix->has_upper[s][l]) {
+        ne++;
+        nn += (int64_t)ix->upper[l][s].size();
+      }
+  if (n_entries) *n_entries = ne;
+  if (n_neighbours) *n_neighbours = nn;
+  if (entry_point) *entry_point = ix->entry;
+  if (max_level) *max_level = ix->max_level;
+  return HNSW_OK;
+}
+
+int hnsw_index_graph(const hnsw_index_t *ix, int32_t *entry_level, int64_t *entry_item, int64_t *entry_offsets,
+                     int64_t *entry_neighbours) {
+  if (!ix || !entry_level || !entry_item || !entry_offsets) return fail(HNSW_EINVAL, "NULL argument");
+  int64_t e = 0, pos = 0;
+  entry_offsets[0] = 0;
+  auto emit = [&](int level, int64_t item, const std::vector<uint32_t> &list) {
+    entry_level[e] = level;
+    entry_item[e] = item;
+    for (uint32_t v : list) entry_neighbours[pos++] = v;
+    entry_offsets[++e] = pos;
+  };
+  for (int64_t i = 0; i < ix->n; ++i)
+    if (ix->has0[(size_t)i]) emit(0, i, ix->level0[(size_t)i]);
+  std::vector<int64_t> slot_item(ix->has_upper.size(), -1);
+  for (int64_t i = 0; i < ix->n; ++i)
+    if (ix->upper_slot_h[(size_t)i] >= 0) slot_item[(size_t)ix->upper_slot_h[(size_t)i]] = i;
+  for (size_t l = 0; l < ix->upper.size(); ++l)
+    for (size_t s = 0; s < ix->upper[l].size(); ++s)
+      if (l < ix->has_upper[s].size() && ix->has_upper[s][l]) emit((int)l + 1, slot_item[s], ix->upper[l][s]);
+  return HNSW_OK;
+}
+
+int hnsw_index_get_vectors(const hnsw_index_t *ix, int64_t i0, int64_t n, float *out) {
+  if (!ix || !out || i0 < 0 || n < 0 || i0 + n > ix->n) return fail(HNSW_EINVAL, "range outside the index");
+  if (n == 0) return HNSW_OK;
+  HTRY(hipSetDevice(ix->device));
+  Buf tmp;
+  HTRY(tmp.reserve((size_t)n * ix->d * 4));
+  const int64_t e = n * ix->d;
+  hipLaunchKernelGGL(hnsw_rows_to_f32, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, 0, ix->x.as<_Float16>(), i0, n, ix->d,
+                     ix->dpad, tmp.as<float>());
+  HTRY(hipGetLastError());
+  HTRY(hipMemcpy(out, tmp.p, (size_t)e * 4, hipMemcpyDeviceToHost));
+  return HNSW_OK;
+}
+
+int hnsw_index_destroy(hnsw_index_t *ix) {
+  delete ix;
+  return HNSW_OK;
+}
+
+int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, int32_t ef, float *out_dist, int64_t *out_ids,
+                int32_t *out_counts) {
+  if (!ix || !queries || !out_dist || !out_ids || !out_counts) return fail(HNSW_EINVAL, "NULL argument");
+  if (nq < 1) return fail(HNSW_EINVAL, "nq must be positive");
+  if (k < 1 || ef < 1) return fail(HNSW_EINVAL, "k and ef must be positive");
+  const int beam = std::max(ef, k);  // HnswIndex.java:545
+  if (beam > MAX_EF) return fail(HNSW_ELIMIT, "max(ef, k) above 1024");
+  ix->last_dist = ix->last_exp = 0;
+  ix->last_spilled = 0;
+  ix->last_ms = 0;
+  if (ix->entry < 0) {  // metadata.getEntryPoint() absent: Collections.emptyList() (:550-552)
+    for (int32_t q = 0; q < nq; ++q) out_counts[q] = 0;
+    return HNSW_OK;
+  }
+  HTRY(hipSetDevice(ix->device));
+  const int64_t vwords = (ix->n + 31) / 32;
+  // concurrent queries per launch: bounded by the visited bitmaps (<= 2 GiB of them)
+  int64_t per_launch = std::min<int64_t>(nq, std::max<int64_t>(64, (int64_t)(2ull << 30) / (vwords * 4)));
+  per_launch = std::min<int64_t>(per_launch, 1 << 16);
+  HTRY(ix->q_in.reserve((size_t)nq * ix->d * 4));
+  HTRY(ix->q.reserve((size_t)nq * ix->dpad * sizeof(_Float16)));
+  HTRY(ix->visited.reserve((size_t)per_launch * vwords * 4));
+  HTRY(ix->o_dist.reserve((size_t)nq * k * 4));
+  HTRY(ix->o_ids.reserve((size_t)nq * k * 8));
+  HTRY(ix->o_cnt.reserve((size_t)nq * 4));
+  HTRY(ix->spill.reserve((size_t)nq * 4));
+  HTRY(ix->stats.reserve(16));
+  hipStream_t st = 0;
+  HTRY(hipMemcpyAsync(ix->q_in.p, queries, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(hnsw_prep_rows, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, ix->q_in.as<float>(), (int64_t)nq, ix->d,
+                     ix->dpad, ix->metric == HNSW_METRIC_COSINE ? 1 : 0, ix->q.as<_Float16>());
+  HTRY(hipGetLastError());
+  HTRY(hipMemsetAsync(ix->stats.p, 0, 16, st));
+  HTRY(hipMemsetAsync(ix->spill.p, 0, (size_t)nq * 4, st));
+
+  SearchArgs a;
+  a.x = ix->x.as<_Float16>();
+  a.adj0 = ix->adj0.as<uint32_t>();
+  a.upper_slot = ix->upper_slot.as<int32_t>();
+  a.upper_base = ix->upper_base.as<int32_t>();
+  a.upper_adj = ix->upper_adj.as<uint32_t>();
+  a.ids = ix->has_ids ? ix->ids.as<int64_t>() : nullptr;
+  a.visited = ix->visited.as<uint32_t>();
+  a.gc = nullptr;
+  a.gw = nullptr;
+  a.out_dist = ix->o_dist.as<float>();
+  a.out_ids = ix->o_ids.as<int64_t>();
+  a.out_counts = ix->o_cnt.as<int32_t>();
+  a.spill = ix->spill.as<int32_t>();
+  a.stats = ix->stats.as<unsigned long long>();
+  a.vwords = vwords;
+  a.dpad = ix->dpad;
+  a.chunks = ix->dpad / 64;
+  a.m = ix->m;
+  a.m0 = ix->m0;
+  a.metric = ix->metric;
+  a.k = k;
+  a.ef = beam;
+  a.max_level = ix->max_level;
+  a.entry = (uint32_t)ix->entry;
+  a.ccap_lds = CCAP_LDS;
+  if (const char *e = getenv("HNSW_DEBUG_CCAP")) a.ccap_lds = std::min(CCAP_LDS, std::max(1, atoi(e)));  // exercises the spill path
+
+  HTRY(hipEventRecord(ix->ev[0], st));
+  for (int64_t q0 = 0; q0 < nq; q0 += per_launch) {
+    const int64_t m = std::min<int64_t>(per_launch, nq - q0);
+    HTRY(hipMemsetAsync(ix->visited.p, 0, (size_t)m * vwords * 4, st));
+    SearchArgs b = a;
+    b.q = ix->q.as<_Float16>() + q0 * ix->dpad;
+    b.qlist = nullptr;
+    b.out_dist = a.out_dist + q0 * k;
+    b.out_ids = a.out_ids + q0 * k;
+    b.out_counts = a.out_counts + q0;
+    b.spill = a.spill + q0;
+    launch_search_any(a.chunks, false, (int)m, b, st);
+    HTRY(hipGetLastError());
+  }
+  // queries whose candidate queue outgrew LDS: again, with the queues in global memory
+  std::vector<int32_t> spill((size_t)nq);
+  HTRY(hipMemcpyAsync(spill.data(), ix->spill.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  HTRY(hipStreamSynchronize(st));
+  std::vector<int32_t> redo;
+  for (int32_t q = 0; q < nq; ++q)
+    if (spill[(size_t)q]) redo.push_back(q);
+  ix->last_spilled = (int32_t)redo.size();
+  if (!redo.empty()) {
+    const int64_t batch = std::min<int64_t>((int64_t)redo.size(), std::min<int64_t>(per_launch, 256));
+    HTRY(ix->gc.reserve((size_t)batch * CCAP_GLOBAL * sizeof(HEntry)));
+    HTRY(ix->gw.reserve((size_t)batch * (MAX_EF + 1) * sizeof(HEntry)));
+    HTRY(ix->qlist.reserve(redo.size() * 4));
+    HTRY(hipMemcpyAsync(ix->qlist.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
+    for (size_t r0 = 0; r0 < redo.size(); r0 += (size_t)batch) {
+      const int64_t m = std::min<int64_t>(batch, (int64_t)(redo.size() - r0));
+      HTRY(hipMemsetAsync(ix->visited.p, 0, (size_t)m * vwords * 4, st));
+      SearchArgs b = a;
+      b.q = ix->q.as<_Float16>();
+      b.qlist = ix->qlist.as<int32_t>() + r0;
+      b.gc = ix->gc.as<HEntry>();
+      b.gw = ix->gw.as<HEntry>();
+      launch_search_any(a.chunks, true, (int)m, b, st);
+      HTRY(hipGetLastError());
+    }
+    HTRY(hipMemcpyAsync(spill.data(), ix->spill.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    HTRY(hipStreamSynchronize(st));
+    for (int32_t q : redo)
+      if (spill[(size_t)q]) return fail(HNSW_ELIMIT, "candidate queue above 131072 entries");
+  }
+  HTRY(hipEventRecord(ix->ev[1], st));
+  unsigned long long stats[2] = {0, 0};
+  HTRY(hipMemcpyAsync(stats, ix->stats.p, 16, hipMemcpyDeviceToHost, st));
+  HTRY(hipMemcpyAsync(out_dist, ix->o_dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+  HTRY(hipMemcpyAsync(out_ids, ix->o_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+  HTRY(hipMemcpyAsync(out_counts, ix->o_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  HTRY(hipStreamSynchronize(st));
+  ix->last_dist = (int64_t)stats[0];
+  ix->last_exp = (int64_t)stats[1];
+  (void)hipEventElapsedTime(&ix->last_ms, ix->ev[0], ix->ev[1]);
+  return HNSW_OK;
+}
+
+int hnsw_last_stats(const hnsw_index_t *ix, int64_t *distance_evals, int64_t *expansions, int32_t *spilled_queries,
+                    float *kernel_ms) {
+  if (!ix) return fail(HNSW_EINVAL, "NULL index");
+  if (distance_evals) *distance_evals = ix->last_dist;
+  if (expansions) *expansions = ix->last_exp;
+  if (spilled_queries) *spilled_queries = ix->last_spilled;
+  if (kernel_ms) *kernel_ms = ix->last_ms;
+  return HNSW_OK;
+}
+
+}  // extern "C"
