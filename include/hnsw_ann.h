@@ -14,8 +14,8 @@
  * The graph is data: `Map<HnswNode(level, item), ImmutableList<item>>` + HnswMeta(maxLevel, entryPoint)
  * (HnswIndex.java:56-72), what HnswIndexIOUtil reads from an index directory.  hnsw_index_build takes
  * exactly that, as flat arrays.  hnsw_index_build_insert builds a graph with the reference's insertion
- * algorithm (HnswIndex.java:137-200,384-440,479-526) on the host, single-threaded and deterministic; the
- * reference builds offline and any graph it wrote can be loaded instead.
+ * algorithm (HnswIndex.java:137-200,384-440,479-526) on the host; the reference builds offline (SURVEY 8
+ * row D4) and any graph it wrote can be loaded instead.
  *
  * Search results are a function of (graph, float distances): the walk reproduces the reference step by
  * step, including java.util.PriorityQueue's sift order, so equal distances are handled as the JVM would.
@@ -54,10 +54,13 @@ int hnsw_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const
                      const int64_t *entry_item, const int64_t *entry_offsets, const int64_t *entry_neighbours,
                      hnsw_index_t **out);
 
-/* Build the graph by inserting items 0..n-1 in order (HnswIndex.insert), then load it.
- * Level draw: (int)(-ln(U) / ln(max_m)) with U from a 64-bit mixer of (seed, item) (HnswIndex.java:118,369-371). */
+/* Build the graph with the reference's insertion algorithm (HnswIndex.insert), then load it.
+ * Level draw: (int)(-ln(U) / ln(max_m)) with U from a 64-bit mixer of (seed, item) (HnswIndex.java:118,369-371).
+ * n_threads = 1 inserts items 0..n-1 in order: deterministic.  With more host threads items are inserted
+ * concurrently under per-item locks, as the reference's writers do (HnswIndex.java:150-200): the graph then
+ * depends on the interleaving (and, as the reference notes at :376-380, may miss a few links). */
 int hnsw_index_build_insert(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
-                            int32_t max_m, int32_t ef_construction, uint64_t seed, hnsw_index_t **out);
+                            int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t n_threads, hnsw_index_t **out);
 
 /* The graph back as flat arrays (two calls: sizes, then contents) and the stored (fp16-rounded) vectors. */
 int hnsw_index_graph_size(const hnsw_index_t *index, int64_t *n_entries, int64_t *n_neighbours, int64_t *entry_point,

@@ -141,3 +141,23 @@ def test_degenerate_indexes(pkg, oracle):
     one.close()
     with pytest.raises(pkg.hnsw_ann.HnswError):
         pkg.hnsw_ann.Hnsw.build(m, np.ones((4, 8), np.float32), max_m=64)
+
+
+def test_concurrent_builder_gives_a_searchable_graph(pkg, oracle):
+    """n_threads > 1: the graph depends on the interleaving, the walk over it is still the reference's walk."""
+    m = pkg.dense_ann.DistanceMetric.Cosine
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((6000, 48)).astype(np.float32)
+    ix = pkg.hnsw_ann.Hnsw.build(m, x, max_m=12, ef_construction=60, seed=3, n_threads=6)
+    lv, it, off, nb, entry, max_level = ix.graph()
+    assert (lv == 0).sum() == len(x) and np.diff(off)[lv == 0].max() <= 24
+    q = rng.standard_normal((20, 48)).astype(np.float32)
+    ids, _, cnt = _compare(pkg, oracle, ix, m, q, 10, 200)
+    bf = pkg.dense_ann.BruteForceIndex.build(m, x)
+    t_ids, _, _ = bf.search(q, 10)
+    bf.close()
+    assert np.mean([len(set(ids[i, :cnt[i]]) & set(t_ids[i])) / 10 for i in range(20)]) > 0.85
+    one = pkg.hnsw_ann.Hnsw.build(m, x[:1500], max_m=12, ef_construction=60, seed=3, n_threads=1)
+    two = pkg.hnsw_ann.Hnsw.build(m, x[:1500], max_m=12, ef_construction=60, seed=3, n_threads=1)
+    assert all(np.array_equal(a, b) for a, b in zip(one.graph()[:4], two.graph()[:4])), "one thread: deterministic"
+    ix.close(); one.close(); two.close()

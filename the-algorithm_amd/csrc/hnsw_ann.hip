@@ -27,9 +27,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <string>
-#include <unordered_map>
+#include <thread>
 #include <vector>
 
 #include "../../include/hnsw_ann.h"
@@ -419,51 +421,79 @@ struct hnsw_index {
 
 namespace {
 
-// graph under construction / being loaded: lists[level][item]
+// graph under construction / being loaded.  Dense rows: item i owns rows base[i] .. base[i] + top[i] (levels
+// 0..top[i]); `has` says whether the reference's map holds the key HnswNode(level, item) at all.
+// One lock per stripe of items guards a row's read-modify-write, so the builder can run on several
+// host threads (the reference inserts concurrently too, HnswIndex.java:150-200); at most one lock is
+// ever held, so there is nothing to deadlock on.
 struct HostGraph {
   int64_t n = 0;
   int m = 0, m0 = 0;
   int max_level = -1;  // HnswIndex.java:97
   int64_t entry = -1;
-  std::vector<std::vector<uint32_t>> l0;  // [n]
-  std::vector<uint8_t> has0;
-  std::vector<std::unordered_map<uint32_t, std::vector<uint32_t>>> up;  // [level - 1]
-  const std::vector<uint32_t> *get(int level, uint32_t item) const {  // getConnectionListForRead
-    if (level == 0) return has0[item] ? &l0[item] : nullptr;
-    if (level - 1 >= (int)up.size()) return nullptr;
-    auto it = up[(size_t)level - 1].find(item);
-    return it == up[(size_t)level - 1].end() ? nullptr : &it->second;
+  std::vector<int32_t> top;
+  std::vector<int64_t> base;
+  std::vector<std::vector<uint32_t>> rows;
+  std::vector<uint8_t> has;
+  std::unique_ptr<std::mutex[]> locks;
+  static constexpr size_t STRIPES = 8192;
+  std::mutex meta;
+
+  void init(int64_t n_, int m_, const std::vector<int32_t> &tops) {
+    n = n_;
+    m = m_;
+    m0 = 2 * m_;
+    top = tops;
+    base.assign((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) base[(size_t)i + 1] = base[(size_t)i] + top[(size_t)i] + 1;
+    rows.assign((size_t)base[(size_t)n], {});
+    has.assign((size_t)base[(size_t)n], 0);
+    locks.reset(new std::mutex[STRIPES]);
+  }
+  std::mutex &lock_of(uint32_t item) { return locks[item % STRIPES]; }
+  // getConnectionListForRead: a copy of the list, empty when the key is absent
+  std::vector<uint32_t> read(int level, uint32_t item) {
+    if (level > top[item]) return {};
+    std::lock_guard<std::mutex> lk(lock_of(item));
+    return rows[(size_t)(base[item] + level)];
+  }
+  bool exists(int level, uint32_t item) const { return level <= top[item] && has[(size_t)(base[item] + level)]; }
+  void put_locked(int level, uint32_t item, std::vector<uint32_t> list) {  // caller holds lock_of(item)
+    rows[(size_t)(base[item] + level)] = std::move(list);
+    has[(size_t)(base[item] + level)] = 1;
   }
   void put(int level, uint32_t item, std::vector<uint32_t> list) {
-    if (level == 0) {
-      l0[item] = std::move(list);
-      has0[item] = 1;
-    } else {
-      if ((int)up.size() < level) up.resize((size_t)level);
-      up[(size_t)level - 1][item] = std::move(list);
-    }
+    std::lock_guard<std::mutex> lk(lock_of(item));
+    put_locked(level, item, std::move(list));
   }
 };
 
+// stored rows on the host, fp16-rounded, each 64-element block transposed ([e][j] instead of [j][e]) so that
+// the 8 partial sums of the fixed summation order are the lanes of one SIMD accumulator
 struct HostVectors {
-  const float *x;  // fp16-rounded, [n][dpad]
-  int dpad, metric;
-  float distance(uint32_t a, uint32_t b) const { return distance(x + (size_t)a * dpad, b); }
-  float distance(const float *q, uint32_t b) const {
-    const float *y = x + (size_t)b * dpad;
-    float p[8];
-    for (int j = 0; j < 8; ++j) {
-      float acc = 0.0f;
-      for (int c = j; c < dpad / 8; c += 8)
-        for (int e = 0; e < 8; ++e) {
-          if (metric == HNSW_METRIC_L2) {
-            const float t = q[c * 8 + e] - y[c * 8 + e];
-            acc = acc + t * t;
-          } else {
-            acc = acc + q[c * 8 + e] * y[c * 8 + e];
-          }
+  std::vector<float> t;
+  int dpad = 0, metric = 0;
+  void load(const std::vector<float> &rows, int64_t n, int dpad_, int metric_) {
+    dpad = dpad_;
+    metric = metric_;
+    t.resize(rows.size());
+    for (int64_t i = 0; i < n; ++i)
+      for (int b = 0; b < dpad / 64; ++b)
+        for (int j = 0; j < 8; ++j)
+          for (int e = 0; e < 8; ++e) t[(size_t)i * dpad + b * 64 + e * 8 + j] = rows[(size_t)i * dpad + b * 64 + j * 8 + e];
+  }
+  float distance(uint32_t a, uint32_t b) const {
+    const float *q = t.data() + (size_t)a * dpad, *y = t.data() + (size_t)b * dpad;
+    float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (metric == HNSW_METRIC_L2) {
+      for (int k = 0; k < dpad; k += 8)
+        for (int j = 0; j < 8; ++j) {
+          const float d = q[k + j] - y[k + j];
+          p[j] = p[j] + d * d;
         }
-      p[j] = acc;
+    } else {
+      for (int k = 0; k < dpad; k += 8)
+        for (int j = 0; j < 8; ++j) p[j] = p[j] + q[k + j] * y[k + j];
     }
     const float r0 = p[0] + p[1], r2 = p[2] + p[3], r4 = p[4] + p[5], r6 = p[6] + p[7];
     return finish_distance(metric, (r0 + r2) + (r4 + r6));
@@ -490,7 +520,7 @@ struct JQueue {
   }
 };
 
-struct Builder {
+struct Builder {  // one per host thread
   HostGraph &g;
   const HostVectors &v;
   int ef_construction;
@@ -505,10 +535,7 @@ struct Builder {
         bool changed = true;
         while (changed) {
           changed = false;
-          const std::vector<uint32_t> *list = g.get(level, cur);
-          if (!list) continue;
-          const std::vector<uint32_t> snapshot = *list;
-          for (uint32_t nn : snapshot) {
+          for (uint32_t nn : g.read(level, cur)) {
             const float t = v.distance(item, nn);
             if (t < cur_dist) {
               cur_dist = t;
@@ -533,9 +560,7 @@ struct Builder {
       const HEntry cand = cq.q[0];
       if (cand.dist > lower) break;
       cq.poll();
-      const std::vector<uint32_t> *list = g.get(level, cand.node);
-      if (!list) continue;
-      for (uint32_t nn : *list) {
+      for (uint32_t nn : g.read(level, cand.node)) {
         if (stamp[nn] == epoch) continue;
         stamp[nn] = epoch;
         const float dist = v.distance(item, nn);
@@ -587,8 +612,8 @@ struct Builder {
     const int M = level == 0 ? g.m0 : g.m;
     for (uint32_t nn : neighbours) {
       if (nn == item) continue;
-      const std::vector<uint32_t> *cur = g.get(level, nn);
-      std::vector<uint32_t> conn = cur ? *cur : std::vector<uint32_t>();
+      std::lock_guard<std::mutex> lk(g.lock_of(nn));  // the neighbour's write lock (:406-435)
+      std::vector<uint32_t> conn = g.rows[(size_t)(g.base[nn] + level)];
       if ((int)conn.size() < M) {
         conn.push_back(item);
       } else {
@@ -597,24 +622,32 @@ struct Builder {
         q.add(HEntry{v.distance(nn, item), item});
         conn = select(q, M);
       }
-      g.put(level, nn, std::move(conn));
+      g.put_locked(level, nn, std::move(conn));
     }
     return neighbours.empty() ? item : neighbours[0];
   }
 
   void insert(uint32_t item, int cur_level) {  // HnswIndex.java:137-200
-    if (g.entry >= 0) {
-      uint32_t cur = (uint32_t)g.entry;
-      const int max_layer = g.max_level;
+    int64_t entry;
+    int max_layer;
+    bool hold_meta = false;
+    g.meta.lock();
+    entry = g.entry;
+    max_layer = g.max_level;
+    if (cur_level > max_layer) hold_meta = true;  // the global lock: this insert may move the entry point (:173-183)
+    else g.meta.unlock();
+    if (entry >= 0) {
+      uint32_t cur = (uint32_t)entry;
       if (cur_level < max_layer) cur = best_entry(cur, item, max_layer, cur_level);
       for (int level = std::min(cur_level, max_layer); level >= 0; --level) {
         const JQueue cands = search_layer(item, cur, ef_construction, level);
         cur = connect(item, cands, level);
       }
     }
-    if (cur_level > g.max_level) {  // HnswMeta starts at (-1, empty): the first item always takes this branch
+    if (hold_meta) {  // HnswMeta starts at (-1, empty): the first item always takes this branch
       g.max_level = cur_level;
       g.entry = item;
+      g.meta.unlock();
     }
   }
 };
@@ -623,46 +656,48 @@ int upload_graph(hnsw_index *ix, const HostGraph &g) {
   const int64_t n = ix->n;
   ix->entry = g.entry;
   ix->max_level = std::max(g.max_level, 0);
-  ix->level0 = g.l0;
-  ix->has0 = g.has0;
-  std::vector<uint32_t> adj0((size_t)n * (ix->m0 + 1), 0);
+  ix->level0.assign((size_t)n, {});
+  ix->has0.assign((size_t)n, 0);
+  std::vector<uint32_t> adj0((size_t)std::max<int64_t>(n, 1) * (ix->m0 + 1), 0);
   for (int64_t i = 0; i < n; ++i) {
-    const auto &l = g.l0[(size_t)i];
+    const auto &l = g.rows[(size_t)g.base[(size_t)i]];
+    ix->level0[(size_t)i] = l;
+    ix->has0[(size_t)i] = g.has[(size_t)g.base[(size_t)i]];
     adj0[(size_t)i * (ix->m0 + 1)] = (uint32_t)l.size();
     std::copy(l.begin(), l.end(), adj0.begin() + (size_t)i * (ix->m0 + 1) + 1);
   }
-  // upper levels: slot per node that has an entry above level 0, rows = its top level
-  std::vector<int32_t> top((size_t)n, 0);
-  for (size_t l = 0; l < g.up.size(); ++l)
-    for (const auto &kv : g.up[l]) top[kv.first] = std::max(top[kv.first], (int32_t)l + 1);
-  ix->upper_slot_h.assign((size_t)n, -1);
+  // upper levels: slot per node with storage above level 0, rows = its top level
+  ix->upper_slot_h.assign((size_t)std::max<int64_t>(n, 1), -1);
   ix->upper_base_h.assign(1, 0);
+  int top_all = 0;
   for (int64_t i = 0; i < n; ++i)
-    if (top[(size_t)i] > 0) {
+    if (g.top[(size_t)i] > 0) {
       ix->upper_slot_h[(size_t)i] = (int32_t)ix->upper_base_h.size() - 1;
-      ix->upper_base_h.push_back(ix->upper_base_h.back() + top[(size_t)i]);
+      ix->upper_base_h.push_back(ix->upper_base_h.back() + g.top[(size_t)i]);
+      top_all = std::max(top_all, g.top[(size_t)i]);
     }
   const int64_t rows = ix->upper_base_h.back();
   std::vector<uint32_t> uadj((size_t)std::max<int64_t>(rows, 1) * (ix->m + 1), 0);
-  ix->upper.assign(g.up.size(), {});
   const size_t n_slots = ix->upper_base_h.size() - 1;
+  ix->upper.assign((size_t)top_all, std::vector<std::vector<uint32_t>>(n_slots));
   ix->has_upper.assign(n_slots, {});
-  for (size_t s = 0; s < n_slots; ++s) ix->has_upper[s].assign((size_t)(ix->upper_base_h[s + 1] - ix->upper_base_h[s]), 0);
-  for (size_t l = 0; l < g.up.size(); ++l) {
-    ix->upper[l].assign(n_slots, {});
-    for (const auto &kv : g.up[l]) {
-      const int32_t s = ix->upper_slot_h[kv.first];
-      ix->upper[l][(size_t)s] = kv.second;
-      ix->has_upper[(size_t)s][l] = 1;
-      uint32_t *row = uadj.data() + (size_t)(ix->upper_base_h[(size_t)s] + (int32_t)l) * (ix->m + 1);
-      row[0] = (uint32_t)kv.second.size();
-      std::copy(kv.second.begin(), kv.second.end(), row + 1);
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t sl = ix->upper_slot_h[(size_t)i];
+    if (sl < 0) continue;
+    ix->has_upper[(size_t)sl].assign((size_t)g.top[(size_t)i], 0);
+    for (int l = 1; l <= g.top[(size_t)i]; ++l) {
+      const auto &list = g.rows[(size_t)(g.base[(size_t)i] + l)];
+      ix->upper[(size_t)l - 1][(size_t)sl] = list;
+      ix->has_upper[(size_t)sl][(size_t)l - 1] = g.has[(size_t)(g.base[(size_t)i] + l)];
+      uint32_t *row = uadj.data() + (size_t)(ix->upper_base_h[(size_t)sl] + l - 1) * (ix->m + 1);
+      row[0] = (uint32_t)list.size();
+      std::copy(list.begin(), list.end(), row + 1);
     }
   }
   HTRY(ix->adj0.reserve(adj0.size() * 4));
   HTRY(hipMemcpy(ix->adj0.p, adj0.data(), adj0.size() * 4, hipMemcpyHostToDevice));
-  HTRY(ix->upper_slot.reserve((size_t)n * 4));
-  HTRY(hipMemcpy(ix->upper_slot.p, ix->upper_slot_h.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  HTRY(ix->upper_slot.reserve(ix->upper_slot_h.size() * 4));
+  HTRY(hipMemcpy(ix->upper_slot.p, ix->upper_slot_h.data(), ix->upper_slot_h.size() * 4, hipMemcpyHostToDevice));
   HTRY(ix->upper_base.reserve(ix->upper_base_h.size() * 4));
   HTRY(hipMemcpy(ix->upper_base.p, ix->upper_base_h.data(), ix->upper_base_h.size() * 4, hipMemcpyHostToDevice));
   HTRY(ix->upper_adj.reserve(uadj.size() * 4));
@@ -750,18 +785,19 @@ int hnsw_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const
   std::unique_ptr<hnsw_index> ix;
   int rc = create_index(device, metric, n, d, vectors, ids, max_m, ix, nullptr);
   if (rc) return rc;
+  std::vector<int32_t> tops((size_t)n, 0);
+  for (int64_t e = 0; e < n_entries; ++e) {
+    if (entry_level[e] < 0 || entry_level[e] > max_level || entry_item[e] < 0 || entry_item[e] >= n)
+      return fail(HNSW_EINVAL, "graph entry out of range");
+    tops[(size_t)entry_item[e]] = std::max(tops[(size_t)entry_item[e]], entry_level[e]);
+  }
   HostGraph g;
-  g.n = n;
-  g.m = max_m;
-  g.m0 = 2 * max_m;
-  g.l0.assign((size_t)n, {});
-  g.has0.assign((size_t)n, 0);
+  g.init(n, max_m, tops);
   g.entry = entry_point < 0 ? -1 : entry_point;
   g.max_level = max_level;
   for (int64_t e = 0; e < n_entries; ++e) {
     const int level = entry_level[e];
     const int64_t item = entry_item[e];
-    if (level < 0 || level > max_level || item < 0 || item >= n) return fail(HNSW_EINVAL, "graph entry out of range");
     const int64_t b = entry_offsets[e], en = entry_offsets[e + 1];
     if (en < b || en - b > (level == 0 ? g.m0 : g.m)) return fail(HNSW_EINVAL, "neighbour list longer than the level allows");
     std::vector<uint32_t> list;
@@ -778,28 +814,50 @@ int hnsw_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const
 }
 
 int hnsw_index_build_insert(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
-                            int32_t max_m, int32_t ef_construction, uint64_t seed, hnsw_index_t **out) {
+                            int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t n_threads, hnsw_index_t **out) {
   if (!out) return fail(HNSW_EINVAL, "out is NULL");
   if (ef_construction < 1) return fail(HNSW_EINVAL, "ef_construction must be positive");
+  if (n_threads < 1 || n_threads > 256) return fail(HNSW_EINVAL, "n_threads must be in 1..256");
   std::unique_ptr<hnsw_index> ix;
   std::vector<float> rows;
   int rc = create_index(device, metric, n, d, vectors, ids, max_m, ix, &rows);
   if (rc) return rc;
-  HostGraph g;
-  g.n = n;
-  g.m = max_m;
-  g.m0 = 2 * max_m;
-  g.l0.assign((size_t)n, {});
-  g.has0.assign((size_t)n, 0);
-  HostVectors hv{rows.data(), ix->dpad, metric};
-  Builder b{g, hv, ef_construction, std::vector<uint32_t>((size_t)n, 0), 0};
   const double level_mult = 1.0 / std::log(1.0 * max_m);  // HnswIndex.java:118
+  std::vector<int32_t> levels((size_t)n);
   for (int64_t i = 0; i < n; ++i) {
     const uint64_t h = sann::mix64(seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull));
     const double u = ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740992.0);  // (0, 1]
-    int level = (int)(-std::log(u) * level_mult);                             // getRandomLevel, :369-371
-    if (level > 60) level = 60;
-    b.insert((uint32_t)i, level);
+    levels[(size_t)i] = std::min(60, (int)(-std::log(u) * level_mult));       // getRandomLevel, :369-371
+  }
+  HostGraph g;
+  g.init(n, max_m, levels);
+  HostVectors hv;
+  hv.load(rows, n, ix->dpad, metric);
+  rows.clear();
+  rows.shrink_to_fit();
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, std::max<int64_t>(1, n / 64)));
+  if (nt == 1) {
+    Builder b{g, hv, ef_construction, std::vector<uint32_t>((size_t)n, 0), 0};
+    for (int64_t i = 0; i < n; ++i) b.insert((uint32_t)i, levels[(size_t)i]);
+  } else {
+    // the first items go in one by one (an entry point must exist), the rest concurrently
+    const int64_t warm = std::min<int64_t>(n, 256);
+    {
+      Builder b{g, hv, ef_construction, std::vector<uint32_t>((size_t)n, 0), 0};
+      for (int64_t i = 0; i < warm; ++i) b.insert((uint32_t)i, levels[(size_t)i]);
+    }
+    std::atomic<int64_t> next(warm);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t)
+      pool.emplace_back([&]() {
+        Builder b{g, hv, ef_construction, std::vector<uint32_t>((size_t)n, 0), 0};
+        for (;;) {
+          const int64_t i = next.fetch_add(1);
+          if (i >= n) break;
+          b.insert((uint32_t)i, levels[(size_t)i]);
+        }
+      });
+    for (auto &th : pool) th.join();
   }
   rc = upload_graph(ix.get(), g);
   if (rc) return rc;

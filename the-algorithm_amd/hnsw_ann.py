@@ -22,7 +22,7 @@ PROTOS = {
     "hnsw_index_build": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                    C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "hnsw_index_build_insert": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                          C.c_uint64, C.POINTER(C.c_void_p)]),
+                                          C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
     "hnsw_index_graph_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "hnsw_index_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hnsw_index_get_vectors": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
@@ -70,14 +70,14 @@ class Hnsw:
 
     @classmethod
     def build(cls, metric: DistanceMetric, vectors: np.ndarray, ids: Optional[Sequence[int]] = None, *, max_m: int = 16,
-              ef_construction: int = 200, seed: int = 1, device: int = 0) -> "Hnsw":
+              ef_construction: int = 200, seed: int = 1, n_threads: int = 1, device: int = 0) -> "Hnsw":
         """Insert the vectors one by one with the reference's algorithm (HnswIndex.insert), on the host."""
         lib = _lib()
         v = np.ascontiguousarray(vectors, np.float32)
         i = None if ids is None else np.ascontiguousarray(ids, np.int64)
         h = C.c_void_p()
         _check(lib, lib.hnsw_index_build_insert(device, int(metric), v.shape[0], v.shape[1], _p(v), _p(i), max_m, ef_construction,
-                                                seed, C.byref(h)))
+                                                seed, n_threads, C.byref(h)))
         return cls(h, metric, v.shape[0], v.shape[1], max_m)
 
     @classmethod

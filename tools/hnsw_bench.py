@@ -1,0 +1,66 @@
+"""HNSW walk throughput (BASELINE configs[3]: d=256 fp16 vectors; prod k=200 / ef=800 per SURVEY 8 row D3).
+Builds the graph with the library's host builder (HnswIndex.insert semantics, multi-threaded), searches a batch
+of queries, and reports queries/s, distance evaluations/s, the bytes those gathers move, and recall@k against
+the exhaustive search of the same vectors.  One JSON line per (k, ef)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--vectors", type=int, default=200_000)
+    ap.add_argument("--dim", type=int, default=256)
+    ap.add_argument("--queries", type=int, default=4096)
+    ap.add_argument("--max-m", type=int, default=16)
+    ap.add_argument("--ef-construction", type=int, default=100)
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--configs", default="10:100,200:800")
+    ap.add_argument("--clusters", type=int, default=2000, help="synthetic data: mixture of this many Gaussians")
+    ap.add_argument("--steps", type=int, default=3)
+    a = ap.parse_args()
+    pkg = load_package()
+    m = pkg.dense_ann.DistanceMetric.Cosine
+    rng = np.random.default_rng(0)
+    centres = rng.standard_normal((a.clusters, a.dim)).astype(np.float32)
+    x = centres[rng.integers(0, a.clusters, a.vectors)] + 0.6 * rng.standard_normal((a.vectors, a.dim)).astype(np.float32)
+    q = centres[rng.integers(0, a.clusters, a.queries)] + 0.6 * rng.standard_normal((a.queries, a.dim)).astype(np.float32)
+    t0 = time.time()
+    ix = pkg.hnsw_ann.Hnsw.build(m, x, max_m=a.max_m, ef_construction=a.ef_construction, seed=1, n_threads=a.threads)
+    build_s = time.time() - t0
+    bf = pkg.dense_ann.BruteForceIndex.build(m, x)
+    for cfg in a.configs.split(","):
+        k, ef = (int(v) for v in cfg.split(":"))
+        ix.search(q[:64], k, ef)
+        t0 = time.time()
+        for _ in range(a.steps):
+            ids, dist, cnt = ix.search(q, k, ef)
+        wall = (time.time() - t0) / a.steps
+        st = ix.last_stats()
+        nt = min(256, a.queries)
+        t_ids, _, _ = bf.search(q[:nt], k)
+        recall = float(np.mean([len(set(ids[i, :cnt[i]].tolist()) & set(t_ids[i].tolist())) / k for i in range(nt)]))
+        row_bytes = ((a.dim + 63) // 64 * 64) * 2
+        print(json.dumps({
+            "metric": "hnsw queries/sec", "value": a.queries / wall, "unit": "queries/s",
+            "config": {"workload": f"{a.vectors} x d={a.dim} fp16 Cosine HNSW maxM={a.max_m} efConstruction={a.ef_construction}, "
+                                   f"{a.queries} queries, k={k}, ef={ef}"},
+            "ms_per_batch": wall * 1e3, "kernel_ms": st["kernel_ms"], "recall_at_k": recall,
+            "distance_evals_per_query": st["distance_evals"] / a.queries, "expansions_per_query": st["expansions"] / a.queries,
+            "distance_evals_per_sec": st["distance_evals"] / (st["kernel_ms"] * 1e-3),
+            "roofline": {"bound": "hbm", "achieved": st["distance_evals"] * row_bytes / (st["kernel_ms"] * 1e-3) / 1e9, "peak": 8000.0,
+                         "unit": "GB/s", "frac": st["distance_evals"] * row_bytes / (st["kernel_ms"] * 1e-3) / 8e12,
+                         "note": "random 512-B row gathers; latency-bound walk"},
+            "spilled_queries": st["spilled_queries"], "build_s": build_s, "build_threads": a.threads}), flush=True)
+    ix.close(); bf.close()
+
+
+if __name__ == "__main__":
+    main()
