@@ -99,6 +99,9 @@ def test_large_beam_and_the_global_queue_path(pkg, oracle):
     try:
         _compare(pkg, oracle, ix, m, q, 100, 1024)
         assert ix.last_stats()["spilled_queries"] == len(q)
+        os.environ["HNSW_DEBUG_CCAP"] = "-40"   # same, but through the second tier (one wave with 136 KB of LDS)
+        _compare(pkg, oracle, ix, m, q, 100, 1024)
+        assert ix.last_stats()["spilled_queries"] == len(q)
     finally:
         del os.environ["HNSW_DEBUG_CCAP"]
     with pytest.raises(pkg.hnsw_ann.HnswError):

@@ -54,6 +54,7 @@ constexpr int MAX_D = 512;
 constexpr int MAX_M = 32;        // lists of <= 2*MAX_M = 64 neighbours: one lane each
 constexpr int MAX_EF = 1024;
 constexpr int CCAP_LDS = 2048;   // candidate queue entries in LDS
+constexpr int CCAP_LDS_BIG = 16384;  // second try of a query that overflowed CCAP_LDS: 136 KB of LDS, one wave per CU
 constexpr int CCAP_GLOBAL = 1 << 17;
 
 struct Buf {
@@ -219,8 +220,8 @@ __device__ __forceinline__ void wave_distances(const SearchArgs &a, const float 
 
 template <int CH, bool GLOBALQ>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
-  __shared__ HEntry cq_s[GLOBALQ ? 1 : CCAP_LDS];
-  __shared__ HEntry wq_s[GLOBALQ ? 1 : MAX_EF + 1];
+  extern __shared__ HEntry dyn_s[];  // !GLOBALQ: result queue [ef + 1], then candidate queue [ccap_lds]
+  HEntry *wq_s = dyn_s, *cq_s = dyn_s + a.ef + 1;
   __shared__ uint32_t ul[64];
   __shared__ float ud[64];
   const int lane = threadIdx.x;
@@ -751,20 +752,27 @@ int create_index(int32_t device, int32_t metric, int64_t n, int32_t d, const flo
 }
 
 template <int CH>
-void launch_search(bool globalq, int blocks, const SearchArgs &a, hipStream_t st) {
-  if (globalq) hipLaunchKernelGGL((hnsw_search_kernel<CH, true>), dim3(blocks), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL((hnsw_search_kernel<CH, false>), dim3(blocks), dim3(64), 0, st, a);
+int launch_search(bool globalq, int blocks, const SearchArgs &a, hipStream_t st) {
+  // LDS per wave = the two queues
+  const size_t lds = globalq ? 0 : (size_t)(a.ef + 1 + a.ccap_lds) * sizeof(HEntry);
+  if (globalq) {
+    hipLaunchKernelGGL((hnsw_search_kernel<CH, true>), dim3(blocks), dim3(64), lds, st, a);
+  } else {
+    if (lds > 60 * 1024) HTRY(hipFuncSetAttribute((const void *)hnsw_search_kernel<CH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((hnsw_search_kernel<CH, false>), dim3(blocks), dim3(64), lds, st, a);
+  }
+  return HNSW_OK;
 }
-void launch_search_any(int chunks, bool globalq, int blocks, const SearchArgs &a, hipStream_t st) {
+int launch_search_any(int chunks, bool globalq, int blocks, const SearchArgs &a, hipStream_t st) {
   switch (chunks) {
-    case 1: launch_search<1>(globalq, blocks, a, st); break;
-    case 2: launch_search<2>(globalq, blocks, a, st); break;
-    case 3: launch_search<3>(globalq, blocks, a, st); break;
-    case 4: launch_search<4>(globalq, blocks, a, st); break;
-    case 5: launch_search<5>(globalq, blocks, a, st); break;
-    case 6: launch_search<6>(globalq, blocks, a, st); break;
-    case 7: launch_search<7>(globalq, blocks, a, st); break;
-    default: launch_search<8>(globalq, blocks, a, st); break;
+    case 1: return launch_search<1>(globalq, blocks, a, st);
+    case 2: return launch_search<2>(globalq, blocks, a, st);
+    case 3: return launch_search<3>(globalq, blocks, a, st);
+    case 4: return launch_search<4>(globalq, blocks, a, st);
+    case 5: return launch_search<5>(globalq, blocks, a, st);
+    case 6: return launch_search<6>(globalq, blocks, a, st);
+    case 7: return launch_search<7>(globalq, blocks, a, st);
+    default: return launch_search<8>(globalq, blocks, a, st);
   }
 }
 
@@ -988,8 +996,13 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   a.ef = beam;
   a.max_level = ix->max_level;
   a.entry = (uint32_t)ix->entry;
-  a.ccap_lds = CCAP_LDS;
-  if (const char *e = getenv("HNSW_DEBUG_CCAP")) a.ccap_lds = std::min(CCAP_LDS, std::max(1, atoi(e)));  // exercises the spill path
+  a.ccap_lds = CCAP_LDS;  // every admission enters the candidate queue and stale ones stay: it reaches 2-3x the beam
+  bool skip_tier2 = false;
+  if (const char *e = getenv("HNSW_DEBUG_CCAP")) {  // tests: shrink tier 1; a negative value keeps tier 2, a positive one goes to tier 3
+    const int v = atoi(e);
+    a.ccap_lds = std::min(CCAP_LDS, std::max(1, v < 0 ? -v : v));
+    skip_tier2 = v > 0;
+  }
 
   HTRY(hipEventRecord(ix->ev[0], st));
   for (int64_t q0 = 0; q0 < nq; q0 += per_launch) {
@@ -1002,10 +1015,12 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
     b.out_ids = a.out_ids + q0 * k;
     b.out_counts = a.out_counts + q0;
     b.spill = a.spill + q0;
-    launch_search_any(a.chunks, false, (int)m, b, st);
+    int rc = launch_search_any(a.chunks, false, (int)m, b, st);
+    if (rc) return rc;
     HTRY(hipGetLastError());
   }
-  // queries whose candidate queue outgrew LDS: again, with the queues in global memory
+  // queries whose candidate queue outgrew its LDS allowance: again with a whole CU's worth of LDS each
+  // (tier 2), and whatever still does not fit with the queues in global memory (tier 3)
   std::vector<int32_t> spill((size_t)nq);
   HTRY(hipMemcpyAsync(spill.data(), ix->spill.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
   HTRY(hipStreamSynchronize(st));
@@ -1013,10 +1028,13 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   for (int32_t q = 0; q < nq; ++q)
     if (spill[(size_t)q]) redo.push_back(q);
   ix->last_spilled = (int32_t)redo.size();
-  if (!redo.empty()) {
+  for (int tier = 2; tier <= 3 && !redo.empty(); ++tier) {
+    if (tier == 2 && skip_tier2) continue;
     const int64_t batch = std::min<int64_t>((int64_t)redo.size(), std::min<int64_t>(per_launch, 256));
-    HTRY(ix->gc.reserve((size_t)batch * CCAP_GLOBAL * sizeof(HEntry)));
-    HTRY(ix->gw.reserve((size_t)batch * (MAX_EF + 1) * sizeof(HEntry)));
+    if (tier == 3) {
+      HTRY(ix->gc.reserve((size_t)batch * CCAP_GLOBAL * sizeof(HEntry)));
+      HTRY(ix->gw.reserve((size_t)batch * (MAX_EF + 1) * sizeof(HEntry)));
+    }
     HTRY(ix->qlist.reserve(redo.size() * 4));
     HTRY(hipMemcpyAsync(ix->qlist.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
     for (size_t r0 = 0; r0 < redo.size(); r0 += (size_t)batch) {
@@ -1027,14 +1045,19 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
       b.qlist = ix->qlist.as<int32_t>() + r0;
       b.gc = ix->gc.as<HEntry>();
       b.gw = ix->gw.as<HEntry>();
-      launch_search_any(a.chunks, true, (int)m, b, st);
+      if (tier == 2) b.ccap_lds = CCAP_LDS_BIG;
+      int rc = launch_search_any(a.chunks, tier == 3, (int)m, b, st);
+      if (rc) return rc;
       HTRY(hipGetLastError());
     }
     HTRY(hipMemcpyAsync(spill.data(), ix->spill.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
     HTRY(hipStreamSynchronize(st));
+    std::vector<int32_t> still;
     for (int32_t q : redo)
-      if (spill[(size_t)q]) return fail(HNSW_ELIMIT, "candidate queue above 131072 entries");
+      if (spill[(size_t)q]) still.push_back(q);
+    redo.swap(still);
   }
+  if (!redo.empty()) return fail(HNSW_ELIMIT, "candidate queue above 131072 entries");
   HTRY(hipEventRecord(ix->ev[1], st));
   unsigned long long stats[2] = {0, 0};
   HTRY(hipMemcpyAsync(stats, ix->stats.p, 16, hipMemcpyDeviceToHost, st));
