@@ -30,7 +30,6 @@ namespace sann {
 
 constexpr int WG = 256;
 constexpr int KMAX = 1024;       // >= MaxNumResultsUpperBound (1000), ApproximateCosineSimilarity.scala:41
-constexpr int MERGE_LDS = 2048;  // entries the merge stages in LDS per tournament round
 
 // ---------------------------------------------------------------------------------------------
 // normalisation, ApproximateCosineSimilarity.scala:111-119
@@ -437,11 +436,14 @@ __device__ void lds_radix_cut(const uint64_t *hi, const uint64_t *lo, int n, int
   thr_lo = pre_lo;
 }
 
-// SURV = capacity of the survivor list: 512 when every k of the batch is <= 448 (LDS 40 KB, four
-// workgroups per CU), else 1024.
+// SURV = capacity of the survivor list: 512 when every k of the batch is <= 448, else 1024.  The staging
+// area holds 1536 entries for SURV = 512: 35 KB of LDS in all, FOUR workgroups per CU, so a 1024-query batch
+// merges in one round of workgroups (at 2048 entries it was 44 KB, three per CU, two rounds: twice the time).
 template <int SURV>
 __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, const int32_t *query_list) {
+  constexpr int MERGE_LDS = SURV == 512 ? 1536 : 2048;  // entries staged per tournament round; >= SURV + any per-unit capacity
   __shared__ uint64_t s_hi[MERGE_LDS], s_lo[MERGE_LDS];
+  __shared__ uint8_t s_umap[MERGE_LDS];  // new entry -> unit (relative to the round's first unit; P <= 256)
   __shared__ ulonglong2 s_e2[SURV];  // survivors, packed {score key, id key}
   __shared__ uint64_t s_mm[2];
   __shared__ unsigned s_hist[256];
@@ -496,23 +498,41 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
     const int n_new = s_off[u_end] - base_off;
     const int n = best_n + n_new;
     for (int i = tid; i < best_n; i += WG) { const ulonglong2 v = s_e2[i]; s_hi[i] = v.x; s_lo[i] = v.y; }
-    // flat over the new entries: every thread finds its list by a search in LDS (offsets and
-    // list pointers were preloaded), so all of a thread's global loads are in flight together
-#pragma unroll 4
-    for (int i = tid; i < n_new; i += WG) {
-      const int flat = base_off + i;
-      int u = u_begin;
-      for (int step = 128; step >= 1; step >>= 1) {
-        const int t = u + step;
-        if (t < u_end && s_off[t] <= flat) u = t;
+    // flat index of a new entry -> its unit: eight threads per list fill a byte map, so that the gather
+    // below needs one LDS read per entry and can put all of a thread's global loads in flight together
+    // (a per-entry search made each load wait for the previous one: six dependent round trips)
+    for (int t = tid; t < 8 * (u_end - u_begin); t += WG) {
+      const int u = u_begin + (t >> 3);
+      for (int i = s_off[u] - base_off + (t & 7); i < s_off[u + 1] - base_off && i < MERGE_LDS; i += 8)
+        s_umap[i] = (uint8_t)(u - u_begin);
+    }
+    __syncthreads();
+    {
+      constexpr int R = (MERGE_LDS + WG - 1) / WG;
+      uint64_t kh[R];
+      int64_t kid[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const int i = r * WG + tid;
+        kh[r] = 0;
+        kid[r] = 0;
+        if (i < n_new && i < MERGE_LDS) {
+          const int u = u_begin + s_umap[i];
+          const int fb = s_fb[u];
+          const int j = base_off + i - s_off[u];
+          const uint64_t *key = fb < 0 ? b.cand_key + (unit0 + u) * b.cap : b.cand_key2 + (int64_t)fb * b.cap2;
+          const int64_t *id = fb < 0 ? b.cand_id + (unit0 + u) * b.cap : b.cand_id2 + (int64_t)fb * b.cap2;
+          kh[r] = key[j];
+          kid[r] = id[j];
+        }
       }
-      const int fb = s_fb[u];
-      const int j = flat - s_off[u];
-      const uint64_t *key = fb < 0 ? b.cand_key + (unit0 + u) * b.cap : b.cand_key2 + (int64_t)fb * b.cap2;
-      const int64_t *id = fb < 0 ? b.cand_id + (unit0 + u) * b.cap : b.cand_id2 + (int64_t)fb * b.cap2;
-      if (best_n + i < MERGE_LDS) {
-        s_hi[best_n + i] = key[j];
-        s_lo[best_n + i] = id_key(id[j]);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const int i = r * WG + tid;
+        if (i < n_new && best_n + i < MERGE_LDS) {
+          s_hi[best_n + i] = kh[r];
+          s_lo[best_n + i] = id_key(kid[r]);
+        }
       }
     }
     __syncthreads();
