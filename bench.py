@@ -53,7 +53,7 @@ def main():
                     help="device: generated + indexed on the GPU (any size); numpy: host generator (<= a few M tweets)")
     ap.add_argument("--queries-per-gpu", type=int, default=1024)
     ap.add_argument("--alg", default="cosine", choices=["cosine", "logcosine", "dot"])
-    ap.add_argument("--partitions", type=int, default=0)
+    ap.add_argument("--partitions", type=int, default=0, help="partitions per cluster list at N = 1 (0 = 32); divided by N when sharded")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-queries", type=int, default=16, help="queries checked bit-for-bit against the oracle")
@@ -100,6 +100,12 @@ def main():
     # ---- synthetic corpus + queries; identical on every rank ---------------------
     t0 = time.time()
     nq = args.queries_per_gpu * world
+    nql = args.queries_per_gpu  # queries this rank owns (finalises); it still answers all nq on its shard
+    if world > 1:
+        # a shard holds 1/world of every posting list: keep the (query, partition) units the same size
+        # by partitioning the shard world times less finely
+        p = max(1, (args.partitions or 32) // world)
+        args.partitions = 1 << (p.bit_length() - 1)
     offs, cids, scs = pkg.corpus.make_queries(nq)
     now_ms = pkg.corpus.NOW_MS
     if args.corpus == "device":
@@ -128,37 +134,44 @@ def main():
     stride = qb.stride
     stream = 0
 
-    # ---- multi-GPU plumbing: one packed buffer per rank -> one all_gather -> exact merge ------
+    # ---- multi-GPU plumbing: per-shard answers -> all-to-all by query owner -> exact merge ----------
+    # Rank r owns queries [r*nql, (r+1)*nql).  Every rank answers all nq queries on its tweet-hash shard;
+    # chunk r of each result array goes to rank r (RCCL all-to-all over xGMI: (world-1)/world of
+    # nq*k*16 B leaves each GPU, the same amount arrives), and the owner merges world per-shard lists.
     if world > 1:
         stream = torch.cuda.current_stream().cuda_stream
-        L = pkg.sharding.packed_words(nq, stride)  # int64 words: ids | score bits | counts, map sizes (int32)
-        mine = torch.zeros(L, dtype=torch.int64, device="cuda")
-        gathered = torch.zeros(world * L, dtype=torch.int64, device="cuda")
-        base = mine.data_ptr()
-        o_ids, o_sc, o_cnt, o_msz = pkg.sharding.packed_offsets(nq, stride)
-        qb.bind_outputs(base + o_ids, base + o_sc, base + o_cnt, base + o_msz)
-        g = gathered.data_ptr()
-        out_ids = torch.zeros((nq, stride), dtype=torch.int64, device="cuda")
-        out_sc = torch.zeros((nq, stride), dtype=torch.float64, device="cuda")
-        out_cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
-        out_msz = torch.zeros(nq, dtype=torch.int32, device="cuda")
-        d_k = qb.device_k()
+        s_ids = torch.zeros(nq * stride, dtype=torch.int64, device="cuda")
+        s_sc = torch.zeros(nq * stride, dtype=torch.int64, device="cuda")  # fp64 bit patterns
+        s_cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+        s_msz = torch.zeros(nq, dtype=torch.int32, device="cuda")
+        qb.bind_outputs(s_ids.data_ptr(), s_sc.data_ptr(), s_cnt.data_ptr(), s_msz.data_ptr())
+        r_ids, r_sc, r_cnt, r_msz = (torch.zeros_like(t) for t in (s_ids, s_sc, s_cnt, s_msz))  # [world][nql][...]
+        out_ids = torch.zeros((nql, stride), dtype=torch.int64, device="cuda")
+        out_sc = torch.zeros((nql, stride), dtype=torch.float64, device="cuda")
+        out_cnt = torch.zeros(nql, dtype=torch.int32, device="cuda")
+        out_msz = torch.zeros(nql, dtype=torch.int32, device="cuda")
+        d_k = qb.device_k() + rank * nql * 4
+
+    def exchange(send, recv):
+        if args.backend == "gloo":  # rehearsal: gloo has no all-to-all; gather on the host and slice
+            h = send.cpu()
+            parts = [torch.zeros_like(h) for _ in range(world)]
+            dist.all_gather(parts, h)
+            c = h.numel() // world
+            recv.copy_(torch.cat([p[rank * c:(rank + 1) * c] for p in parts]))
+        else:
+            dist.all_to_all_single(recv, send)
 
     def step():
         qb.run(stream)
+        qb.finish(stream)  # waits for the stream; re-runs whatever the fast path flagged, before anything is sent
         if world > 1:
-            if args.backend == "gloo":
-                torch.cuda.current_stream().synchronize()
-                h_all = torch.zeros(world * L, dtype=torch.int64)
-                dist.all_gather_into_tensor(h_all, mine.cpu())
-                gathered.copy_(h_all)
-            else:
-                dist.all_gather_into_tensor(gathered, mine)
-            rc = lib.sann_merge_shards(local_rank, ctypes.c_void_p(stream), world, nq, stride, L * 8, g + o_ids,
-                                       g + o_sc, g + o_cnt, g + o_msz,
+            for send, recv in ((s_ids, r_ids), (s_sc, r_sc), (s_cnt, r_cnt), (s_msz, r_msz)):
+                exchange(send, recv)
+            rc = lib.sann_merge_shards(local_rank, ctypes.c_void_p(stream), world, nql, stride, 0, r_ids.data_ptr(),
+                                       r_sc.data_ptr(), r_cnt.data_ptr(), r_msz.data_ptr(),
                                        d_k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr())
             assert rc == 0, lib.sann_last_error()
-        qb.finish(stream)  # waits for the stream; re-runs whatever the fast path flagged
 
     def sync():
         if world > 1:
@@ -169,10 +182,10 @@ def main():
             assert lib.sann_device_synchronize(local_rank) == 0
 
     def check_sharded_against_unsharded():
-        """Rehearsal only: rank 0 also builds the whole corpus and checks the merged answer."""
+        """Rehearsal only: rank 0 also builds the whole corpus and checks the merged answer of its queries."""
         full = pkg.ClusterTweetIndex.synthetic(args.tweets, pkg.corpus.N_CLUSTERS, seed=pkg.corpus.CORPUS_SEED,
                                                index_cap=2000, now_ms=now_ms, device=local_rank, n_partitions=args.partitions)
-        qf = pkg.QueryBatch(full, offs, cids, scs, cfg, now_ms=now_ms)
+        qf = pkg.QueryBatch(full, offs[:nql + 1], cids[:offs[nql]], scs[:offs[nql]], cfg, now_ms=now_ms)
         qf.run(); qf.finish()
         f_ids, f_sc, f_cnt, f_msz = qf.results()
         qf.close(); full.close()
@@ -191,12 +204,7 @@ def main():
     unit_ms, merge_ms, n_timed = qb.kernel_times()
     desc_ms = qb.desc_time()
     qb.set_profiling(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # ---- results of the last step -------------------------------------------------------------
+    # ---- results of the last step (this rank's own queries when sharded) -----------------------
     if world > 1:
         torch.cuda.synchronize()
         ids, scores, counts, msz = out_ids.cpu().numpy(), out_sc.cpu().numpy(), out_cnt.cpu().numpy(), out_msz.cpu().numpy()
@@ -204,6 +212,14 @@ def main():
         ids, scores, counts, msz = qb.results()
     st = qb.stats()
     candidates_per_step = int(counts.sum())
+    if world > 1:
+        dev = "cpu" if args.backend == "gloo" else "cuda"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tc = torch.tensor([candidates_per_step], dtype=torch.int64, device=dev)
+        dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+        candidates_per_step = int(tc.item())  # whole job: every rank's queries
     value = candidates_per_step * args.steps / elapsed
 
     if rank != 0:
@@ -214,7 +230,7 @@ def main():
 
     # ---- parity spot check against the oracle (outside the timed region) -----------------------
     oracle = ge.load_oracle()
-    n_check = min(args.check_queries, nq) if (co is not None or world == 1) else 0
+    n_check = min(args.check_queries, nql) if (co is not None or world == 1) else 0
     exact = 0
     if n_check:
         L = host_lists(n_check)
@@ -260,7 +276,7 @@ def main():
 
     # ---- roofline of the dominant kernel (unit kernel: gather + accumulate + select) -----------
     # algorithmic bytes per launch: sum_q P_q*16 + n*12 + k_out*16
-    alg_bytes = int(st.algorithmic_bytes) + candidates_per_step * 16 if world == 1 else int(st.algorithmic_bytes) + int(counts.sum()) * 16
+    alg_bytes = int(st.algorithmic_bytes) + int(counts.sum()) * 16
     unit_avg_ms = unit_ms / max(n_timed, 1)
     achieved = alg_bytes / (unit_avg_ms * 1e-3) / 1e9 if unit_avg_ms > 0 else 0.0
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -282,7 +298,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"batched simclusters-ann, {nq} concurrent user queries, {args.tweets} tweets x 144428 clusters, "
-                               f"top-400, N=50 M=800 {args.alg}, {'1xMI355X' if world == 1 else f'{world}xMI355X tweet-hash shards + RCCL all-gather merge'}",
+                               f"top-400, N=50 M=800 {args.alg}, {'1xMI355X' if world == 1 else f'{world}xMI355X tweet-hash shards + RCCL all-to-all merge'}",
                    "queries": nq, "tweets": args.tweets, "clusters": 144428, "k": 400, "max_scan_clusters": 50,
                    "max_top_tweets_per_cluster": 800, "algorithm": args.alg, "index_cap": 2000,
                    "partitions": index.info().n_partitions, "sharding": "none" if world == 1 else "tweet-hash",
