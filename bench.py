@@ -102,9 +102,12 @@ def main():
     nq = args.queries_per_gpu * world
     nql = args.queries_per_gpu  # queries this rank owns (finalises); it still answers all nq on its shard
     if world > 1:
-        # a shard holds 1/world of every posting list: keep the (query, partition) units the same size
-        # by partitioning the shard world times less finely
-        p = max(1, (args.partitions or 32) // world)
+        # a shard holds 1/world of every posting list: keep the (query, partition) units about the same
+        # size by partitioning the shard world times less finely -- but not below 8 partitions: a unit
+        # must hand over ~k/P candidates and its survivor list holds 160 (measured with
+        # tools/shard_cost.py: at N = 8, P = 4 sends ~100 units per batch to the general path, 1.04 ms
+        # per GPU-step; P = 8 none, 0.65 ms; P = 16 0.78 ms)
+        p = max(8, (args.partitions or 32) // world)
         args.partitions = 1 << (p.bit_length() - 1)
     offs, cids, scs = pkg.corpus.make_queries(nq)
     now_ms = pkg.corpus.NOW_MS
