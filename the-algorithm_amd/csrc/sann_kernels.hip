@@ -437,11 +437,11 @@ __device__ void lds_radix_cut(const uint64_t *hi, const uint64_t *lo, int n, int
 }
 
 // SURV = capacity of the survivor list: 512 when every k of the batch is <= 448, else 1024.  The staging
-// area holds 1536 entries for SURV = 512: 35 KB of LDS in all, FOUR workgroups per CU, so a 1024-query batch
+// area holds 1728 entries for SURV = 512: 39.8 KB of LDS in all, FOUR workgroups per CU, so a 1024-query batch
 // merges in one round of workgroups (at 2048 entries it was 44 KB, three per CU, two rounds: twice the time).
 template <int SURV>
 __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, const int32_t *query_list) {
-  constexpr int MERGE_LDS = SURV == 512 ? 1536 : 2048;  // entries staged per tournament round; >= SURV + any per-unit capacity
+  constexpr int MERGE_LDS = SURV == 512 ? 1728 : 2048;  // entries staged per tournament round; >= SURV + any per-unit capacity
   __shared__ uint64_t s_hi[MERGE_LDS], s_lo[MERGE_LDS];
   __shared__ uint8_t s_umap[MERGE_LDS];  // new entry -> unit (relative to the round's first unit; P <= 256)
   __shared__ ulonglong2 s_e2[SURV];  // survivors, packed {score key, id key}
