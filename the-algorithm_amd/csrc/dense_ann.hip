@@ -21,7 +21,7 @@
 // The [N x nq] score matrix is never written.  Exact top-k without it:
 //   pass A  the same GEMM over a strided sample of the index writes only per-(query, 64-vector tile)
 //           maxima; tau_q = the k-th largest tile maximum is a lower bound of the k-th best score
-//           (k distinct vectors reach it).  The sample is sized so that ~E_TARGET scores pass tau_q.
+//           (k distinct vectors reach it).  The sample is sized so that ~256 sqrt(k) scores pass tau_q.
 //   pass B  the GEMM over the whole index appends every score >= tau_q to a per-query buffer.
 //   refine  a query whose buffer overflowed takes the k-th largest buffered score as a tighter bound
 //           and pass B is repeated for it (never happens at the sizes pass A is tuned for; it is the
@@ -63,7 +63,6 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 constexpr int WAVES = 8;          // per workgroup: 2 per SIMD, 256 VGPRs each
 constexpr int WG = WAVES * 64;
 constexpr int CAP = 8192;         // survivors kept per query
-constexpr int E_TARGET = 2048;    // survivors pass A aims for
 constexpr int MAX_K = 1024;
 constexpr int MAX_D = 512;
 constexpr int MAX_NQ = 4096;     // queries per GEMM launch
@@ -360,7 +359,7 @@ __device__ __forceinline__ void mfma_last_step(float16v (&c)[VB], const half8 (&
 template <int S, int VB, bool EMIT, bool BIAS>
 __global__ __launch_bounds__(W2 * 64) void gemm2_kernel(GemmArgs a) {
   constexpr int CH = S * 64, NB = 3, NCH = CH / (W2 * 64);
-  constexpr int FOLD = (VB * 16 + S - 1) / S;  // accumulator registers folded per k-step
+  constexpr int FOLD = (VB * 16 + S / 2 - 1) / (S / 2);  // accumulator registers folded per k-step (first half of a block)
   extern __shared__ half8 smem[];
   float4 *sbias = (float4 *)(smem + NB * CH);    // [W2][VB][8]
   uint32_t *sb_n = (uint32_t *)(sbias + W2 * VB * 8);  // survivor staging: count (+ 3 words of padding)
@@ -420,13 +419,15 @@ __global__ __launch_bounds__(W2 * 64) void gemm2_kernel(GemmArgs a) {
         if (lane < 32) a.tmax[(int64_t)q * a.pitch + ((int64_t)(a.col0 + blockIdx.x) * W2 + w) * 2 + h] = m;
       }
     } else {
-      // survivors are rare (about E_TARGET per query over the whole index): test per wave, then per
+      // survivors are rare (a few hundred per query over the whole index): test per wave, then per
       // 32-vector block, and only then per element
       const float thr = stau[q];
       float mall = fm[0];
 #pragma unroll
       for (int vb = 1; vb < VB; ++vb) mall = fmaxf(mall, fm[vb]);
-      if (__builtin_amdgcn_ballot_w64(mall >= thr) != 0) {
+      // cold: about one wave-block in six gets here; keeping it out of line keeps the two-block hot loop
+      // (~25 KB of code) contiguous in the 64 KB instruction cache it shares with the neighbouring CU
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(mall >= thr) != 0, 0)) {
         // opaque copy: keeps the 64 positions (and their bound checks) from being hoisted out of the
         // block loop into 64 live registers
         uint32_t vb0 = vbase;
@@ -462,11 +463,8 @@ __global__ __launch_bounds__(W2 * 64) void gemm2_kernel(GemmArgs a) {
   // one query block: MFMAs into cur, epilogue of the previous block on prev
   auto block = [&](auto hp, float16v (&cur)[VB], float16v (&prev)[VB], int qb, int slot) {
     constexpr bool have_prev = decltype(hp)::value;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     const int slot2 = slot == 0 ? 2 : slot - 1;  // (qb + 2) % 3
     const int slot1 = slot == 2 ? 0 : slot + 1;  // (qb + 1) % 3
-    if (qb + 2 < a.nqb) stage(qb + 2, slot2);
     float16v bt[VB];
     if (BIAS) {
 #pragma unroll
@@ -485,6 +483,17 @@ __global__ __launch_bounds__(W2 * 64) void gemm2_kernel(GemmArgs a) {
     const bool more = qb + 1 < a.nqb;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
+      if (s == 1) {
+        // The block's one synchronisation point sits between two MFMA groups, not at the block
+        // boundary: with a single wave per SIMD nothing else keeps the matrix pipe busy while this
+        // wave waits, so the wait is taken with the four MFMAs of step 0 still executing.  It retires
+        // stage qb+1 (issued a block ago: free) and orders the restaging of slot (qb-1) % 3 behind every
+        // wave's last read of it (block qb-1 is over for whoever gets here).  What block qb itself
+        // reads was retired by the previous block's barrier.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (qb + 2 < a.nqb) stage(qb + 2, slot2);
+      }
       // keep the ring 3 fragments ahead; past the end of this block it runs into the next one
       if (s + 3 < S) DANN_LDB(slot, s + 3);
       else if (more) DANN_LDB(slot1, s + 3 - S);
@@ -504,9 +513,13 @@ __global__ __launch_bounds__(W2 * 64) void gemm2_kernel(GemmArgs a) {
           }
         }
       }
-      if constexpr (have_prev) fold(prev, s * FOLD, FOLD);
+      // the previous block's epilogue rides in the shadow of this block's MFMAs: folds in the first
+      // half, the threshold test right behind them
+      if constexpr (have_prev) {
+        if (s < S / 2) fold(prev, s * FOLD, FOLD);
+        if (s == S / 2) finish(prev, qb - 1);
+      }
     }
-    if constexpr (have_prev) finish(prev, qb - 1);
   };
 
   float16v acc0[VB], acc1[VB];
@@ -907,12 +920,15 @@ static int search_chunk(dann_index_t *ix, int32_t nq, const float *queries, int3
   const bool l2 = ix->metric == DANN_METRIC_L2;
   const uint32_t n_full = (uint32_t)(ix->n / wg_vecs);
   const bool tail = n_wg > n_full;
-  // pass-A sample (full tiles only): enough workgroup tiles that ~E_TARGET scores clear tau, at
-  // least 4k tile maxima
+  // pass-A sample (full tiles only).  A larger sample costs GEMM time (2k / E of a full pass) but gives a
+  // tighter tau, i.e. fewer survivors E in pass B, where a survivor takes its wave out of the MFMA stream
+  // for ~1000 cycles (and its three neighbours wait for it at the next barrier).  Measured at k = 10 on
+  // 50M vectors: E = 2048 -> 0.33 + 21.9 ms, E = 405 -> 1.43 + 20.95 ms; the sum is flat in between.
+  const int e_target = (int)std::min(4096.0, std::max(512.0, 256.0 * std::sqrt((double)k)));
   uint32_t n_swg = 0;
   static const bool no_sample = getenv("DANN_NO_SAMPLE") != nullptr;  // debugging: force the refinement path
   if ((int64_t)n_full * WAVES >= k && !no_sample) {
-    uint64_t want = ((uint64_t)2 * k * n_wg + E_TARGET - 1) / E_TARGET;
+    uint64_t want = ((uint64_t)2 * k * n_wg + e_target - 1) / e_target;
     uint64_t floor_wg = ((uint64_t)4 * std::max(k, 64) + WAVES - 1) / WAVES;
     n_swg = (uint32_t)std::min<uint64_t>(n_full, std::max(want, floor_wg));
   }
