@@ -401,12 +401,14 @@ __global__ __launch_bounds__(W2 * 64) void gemm2_kernel(GemmArgs a) {
   float fm[VB];  // running maximum per 32-vector block
   const uint32_t vbase = (uint32_t)(g0 * 32) + 4u * (uint32_t)(lane >> 5);  // + 32 vb + row(i) = position
   const uint32_t n32 = (uint32_t)a.n;
+  // element e of the fold order is register (e / VB) of block (e % VB): consecutive elements belong to
+  // different blocks, so the v_max3 of one k-step are independent of each other (a dependent VALU chain in
+  // the MFMA shadow costs ~3.4 cycles per instruction instead of ~1: tools/micro/mfma_loop.hip)
   auto fold = [&](float16v (&p)[VB], int first, int count) {
 #pragma unroll
     for (int e = first; e < first + count && e < VB * 16; ++e) {
-      const int vb = e >> 4, i = e & 15;
-      float x = p[vb][i];
-      fm[vb] = fmaxf(fm[vb], x);
+      const int vb = e % VB, i = e / VB;
+      fm[vb] = fmaxf(fm[vb], p[vb][i]);
     }
   };
   auto finish = [&](float16v (&p)[VB], int qb) {
@@ -495,8 +497,10 @@ __global__ __launch_bounds__(W2 * 64) void gemm2_kernel(GemmArgs a) {
         if (qb + 2 < a.nqb) stage(qb + 2, slot2);
       }
       // keep the ring 3 fragments ahead; past the end of this block it runs into the next one
+      // (unconditional: behind the last block it re-reads this slot -- a branch here makes the compiler
+      // wait for every outstanding LDS read at the end of each block)
       if (s + 3 < S) DANN_LDB(slot, s + 3);
-      else if (more) DANN_LDB(slot1, s + 3 - S);
+      else DANN_LDB(more ? slot1 : slot, s + 3 - S);
       if (s == S - 1) {
         half8 al[VB];
 #pragma unroll
