@@ -45,6 +45,9 @@ def traffic_bytes(args, nq, world):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="sann", choices=["sann", "dense", "hnsw"],
+                    help="sann (default): the headline metric of BASELINE.json (configs[2]); dense / hnsw: the two legs of "
+                         "configs[3], run through tools/dense_bench.py / tools/hnsw_bench.py on one GPU (their own JSON lines)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -65,6 +68,10 @@ def main():
                          "rehearse the N > 1 code path with several ranks sharing one GPU")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cpu_count, 16))")
     args = ap.parse_args()
+    if args.workload != "sann":
+        import subprocess
+        tool = os.path.join(ROOT, "tools", "dense_bench.py" if args.workload == "dense" else "hnsw_bench.py")
+        sys.exit(subprocess.run([sys.executable, tool, "--steps", str(max(1, min(args.steps, 5)))]).returncode)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
