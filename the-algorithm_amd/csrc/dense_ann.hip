@@ -12,10 +12,10 @@
 //   * the index is stored in HBM already in MFMA A-fragment order -- per block of 32 vectors,
 //     [k-step s][lane][8 halves] with lane (r, h) holding x[r][16s + 8h .. +8] -- so a wave loads its
 //     vectors with perfectly coalesced 1-KiB global_load_dwordx4 and keeps them IN REGISTERS
-//     (VB blocks x S k-steps x 4 VGPRs = 128 VGPRs) for the whole life of the workgroup;
+//     (VB blocks x S k-steps x 4 registers = all 256 AGPRs) for the whole life of the workgroup;
 //   * the queries are pre-arranged once per search in the same fragment order (B operand); blocks of
-//     32 queries are streamed through a double-buffered LDS tile shared by the 8 waves, each wave
-//     reading one conflict-free ds_read_b128 per two MFMAs;
+//     32 queries are streamed through a three-slot LDS ring shared by the 4 waves, each wave reading
+//     one conflict-free ds_read_b128 per four MFMAs;
 //   * C has the query on the lane and 16 vectors in the accumulator registers, so the per-query
 //     reductions of the epilogue (tile maximum, threshold test) are register-local.
 // The [N x nq] score matrix is never written.  Exact top-k without it:
@@ -60,8 +60,8 @@ int fail(int code, const std::string &m) {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-constexpr int WAVES = 8;          // per workgroup: 2 per SIMD, 256 VGPRs each
-constexpr int WG = WAVES * 64;
+constexpr int W2 = 4;             // waves per workgroup: one per SIMD, the whole 512-register file each
+constexpr int TILE_MAXIMA = 2 * W2;  // pass A writes two tile maxima per wave
 constexpr int CAP = 8192;         // survivors kept per query
 constexpr int MAX_K = 1024;
 constexpr int MAX_D = 512;
@@ -202,92 +202,8 @@ struct GemmArgs {
   Survivor *surv;        // [nqb*32][CAP]
 };
 
-template <int S, int VB, bool EMIT>
-__global__ __launch_bounds__(WG) void gemm_kernel(GemmArgs a) {
-  constexpr int CH = S * 64;                  // 16-byte chunks per query block
-  constexpr int NCH = (CH + WG - 1) / WG;
-  __shared__ half8 lds[2][CH];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  // strided sample: launch tile j covers index tile floor(j * total / launch)
-  const uint32_t tile = a.tile0 + (uint32_t)(((uint64_t)blockIdx.x * a.n_wg_total) / a.n_wg_launch);
-  const int64_t g0 = ((int64_t)tile * WAVES + w) * VB;  // first 32-vector block of this wave
-
-  half8 av[VB][S];
-#pragma unroll
-  for (int vb = 0; vb < VB; ++vb)
-#pragma unroll
-    for (int s = 0; s < S; ++s) av[vb][s] = *(const half8 *)&a.xf[((((g0 + vb) * S + s) * 64) + lane) * 8];
-  // per-vector bias of this wave's rows, re-read (broadcast) at every accumulator reset
-  __shared__ float4 sbias[WAVES][VB][8];
-  if (lane < VB * 8) sbias[w][lane >> 3][lane & 7] = *(const float4 *)&a.bias[g0 * 32 + lane * 4];
-
-  const half8 *qsrc = (const half8 *)a.qf;
-  half8 pre[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c)
-    if (t + c * WG < CH) lds[0][t + c * WG] = qsrc[t + c * WG];
-
-  for (int qb = 0; qb < a.nqb; ++qb) {
-    __syncthreads();
-    const int buf = qb & 1;
-    if (qb + 1 < a.nqb) {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-        if (t + c * WG < CH) pre[c] = qsrc[(size_t)(qb + 1) * CH + t + c * WG];
-    }
-    float16v acc[VB];
-#pragma unroll
-    for (int vb = 0; vb < VB; ++vb)
-#pragma unroll
-      for (int i4 = 0; i4 < 4; ++i4) {  // register 4*i4 + j is row 8*i4 + 4*(lane >> 5) + j
-        float4 bv = sbias[w][vb][2 * i4 + (lane >> 5)];
-        acc[vb][4 * i4 + 0] = bv.x;
-        acc[vb][4 * i4 + 1] = bv.y;
-        acc[vb][4 * i4 + 2] = bv.z;
-        acc[vb][4 * i4 + 3] = bv.w;
-      }
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      half8 b = lds[buf][s * 64 + lane];
-#pragma unroll
-      for (int vb = 0; vb < VB; ++vb) acc[vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[vb][s], b, acc[vb], 0, 0, 0);
-    }
-    if (qb + 1 < a.nqb) {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-        if (t + c * WG < CH) lds[buf ^ 1][t + c * WG] = pre[c];
-    }
-    // epilogue: this lane's query is column lane & 31
-    const int q = qb * 32 + (lane & 31);
-    float m = -INFINITY;
-#pragma unroll
-    for (int vb = 0; vb < VB; ++vb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[vb][i]);
-    if (!EMIT) {
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
-      if (lane < 32) a.tmax[(int64_t)q * a.pitch + (int64_t)(a.col0 + blockIdx.x) * WAVES + w] = m;
-    } else {
-      const float thr = a.tau[q];
-      if (m >= thr) {
-#pragma unroll
-        for (int vb = 0; vb < VB; ++vb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            float sc = acc[vb][i];
-            int64_t v = (g0 + vb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            if (sc >= thr && v < a.n) {
-              uint32_t p = atomicAdd(&a.cnt[q], 1u);
-              if (p < (uint32_t)CAP) a.surv[(size_t)q * CAP + p] = Survivor{sc, (uint32_t)v};
-            }
-          }
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// GEMM, second geometry: ONE wave per SIMD with the whole 512-register file, registers placed by hand.
+// The GEMM: ONE wave per SIMD with the whole 512-register file, registers placed by hand.
 //   * the wave's VB x 32 vectors live in the 256 AGPRs (MFMA reads srcA from AGPRs directly); the
 //     MFMAs are inline asm with an "a" constraint so that the allocator keeps them there -- left to
 //     itself hipcc parks them in AGPRs as spill space and copies each fragment back before use;
@@ -305,7 +221,6 @@ __global__ __launch_bounds__(WG) void gemm_kernel(GemmArgs a) {
 //     read only after a barrier that followed the wait that retired it.
 // MFMA hazards the compiler cannot see through the asm: see mfma_last_step.
 // ---------------------------------------------------------------------------------------------
-constexpr int W2 = 4;
 constexpr int SB_CAP = 512;  // survivors a workgroup stages in LDS before touching global memory
 struct Staged {
   float score;
@@ -736,7 +651,7 @@ int pick_geometry(int d, int *S, int *VB) {
   int s = 4;
   while (s * 16 < d) s <<= 1;
   *S = s;
-  *VB = s == 32 ? 1 : 2;
+  *VB = s == 32 ? 2 : 4;  // 32-vector blocks per wave: VB * S * 4 = 256 AGPRs of A fragments
   return DANN_OK;
 }
 
@@ -750,19 +665,12 @@ int alloc_index(dann_index *ix, int device, int metric, int64_t n, int d) {
   ix->metric = metric;
   ix->d = d;
   ix->n = n;
-  const int64_t tile = (int64_t)WAVES * ix->VB * 32;
+  const int64_t tile = (int64_t)W2 * ix->VB * 32;
   ix->n_pad = (n + tile - 1) / tile * tile;
   DTRY(ix->xf.reserve((size_t)ix->n_pad * ix->S * 16 * sizeof(_Float16)));
   DTRY(ix->bias.reserve((size_t)ix->n_pad * sizeof(float)));
   DTRY(hipMemset(ix->xf.p, 0, ix->xf.bytes));
   for (auto &e : ix->ev) DTRY(hipEventCreate(&e));
-  return DANN_OK;
-}
-
-template <int S, int VB>
-int launch_gemm(bool emit, const GemmArgs &a, hipStream_t st) {
-  if (emit) hipLaunchKernelGGL((gemm_kernel<S, VB, true>), dim3(a.n_wg_launch), dim3(WG), 0, st, a);
-  else hipLaunchKernelGGL((gemm_kernel<S, VB, false>), dim3(a.n_wg_launch), dim3(WG), 0, st, a);
   return DANN_OK;
 }
 
@@ -778,20 +686,7 @@ int launch_gemm2(bool emit, bool bias, const GemmArgs &a, hipStream_t st) {
   return DANN_OK;
 }
 
-// geometry 2 (one wave per SIMD) is the default; DANN_GEOMETRY=1 selects the 8-wave kernel (A/B runs)
 int launch_gemm_any(int S, bool emit, bool bias, const GemmArgs &a, hipStream_t st) {
-  static const int geometry = [] {
-    const char *e = getenv("DANN_GEOMETRY");
-    return e ? atoi(e) : 2;
-  }();
-  if (geometry == 1) {
-    switch (S) {
-      case 4: return launch_gemm<4, 2>(emit, a, st);
-      case 8: return launch_gemm<8, 2>(emit, a, st);
-      case 16: return launch_gemm<16, 2>(emit, a, st);
-      default: return launch_gemm<32, 1>(emit, a, st);
-    }
-  }
   switch (S) {
     case 4: return launch_gemm2<4, 4>(emit, bias, a, st);
     case 8: return launch_gemm2<8, 4>(emit, bias, a, st);
@@ -915,7 +810,7 @@ static int search_chunk(dann_index_t *ix, int32_t nq, const float *queries, int3
   DTRY(hipSetDevice(ix->device));
   const int S = ix->S, d = ix->d;
   const int nqb = (nq + 31) / 32, nq_pad = nqb * 32;
-  const int64_t wg_vecs = (int64_t)WAVES * ix->VB * 32;
+  const int64_t wg_vecs = (int64_t)W2 * ix->VB * 32;
   const uint32_t n_wg = (uint32_t)(ix->n_pad / wg_vecs);
 
   // tiles without padding rows run without the per-vector bias for InnerProduct / Cosine (the
@@ -931,12 +826,12 @@ static int search_chunk(dann_index_t *ix, int32_t nq, const float *queries, int3
   const int e_target = (int)std::min(4096.0, std::max(512.0, 256.0 * std::sqrt((double)k)));
   uint32_t n_swg = 0;
   static const bool no_sample = getenv("DANN_NO_SAMPLE") != nullptr;  // debugging: force the refinement path
-  if ((int64_t)n_full * WAVES >= k && !no_sample) {
+  if ((int64_t)n_full * TILE_MAXIMA >= k && !no_sample) {
     uint64_t want = ((uint64_t)2 * k * n_wg + e_target - 1) / e_target;
-    uint64_t floor_wg = ((uint64_t)4 * std::max(k, 64) + WAVES - 1) / WAVES;
+    uint64_t floor_wg = ((uint64_t)4 * std::max(k, 64) + TILE_MAXIMA - 1) / TILE_MAXIMA;
     n_swg = (uint32_t)std::min<uint64_t>(n_full, std::max(want, floor_wg));
   }
-  const int64_t pitch = (int64_t)n_swg * WAVES;
+  const int64_t pitch = (int64_t)n_swg * TILE_MAXIMA;
 
   DTRY(ix->q_in.reserve((size_t)nq * d * sizeof(float)));
   DTRY(ix->qf.reserve((size_t)nq_pad * S * 16 * sizeof(_Float16)));
