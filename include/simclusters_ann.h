@@ -204,9 +204,10 @@ int sann_batch_results(sann_batch_t *batch, int64_t *out_ids, double *out_scores
 int sann_batch_device_results(sann_batch_t *batch, void **d_ids, void **d_scores, void **d_counts,
                               void **d_map_sizes, int32_t *stride);
 int sann_batch_stats(sann_batch_t *batch, sann_batch_stats_t *stats);
-/* Measurement: when enabled, sann_batch_run brackets the unit (gather + accumulate + select)
- * kernel(s) and the merge kernel with HIP events on the launch stream; sann_batch_finish adds
- * the elapsed times to running totals.  Resets the totals. */
+/* Measurement: sann_batch_run brackets kernels with HIP events on the launch stream and sann_batch_finish
+ * adds the elapsed times to running totals.  enable = 1: the unit (gather + accumulate + select) kernel only --
+ * two events per run, what a timed region should carry (every event costs the stream ~5 us); enable = 2: the
+ * descriptor, unit and merge kernels (four events).  0 = off.  Resets the totals. */
 int sann_batch_set_profiling(sann_batch_t *batch, int32_t enable);
 int sann_batch_kernel_times(sann_batch_t *batch, double *unit_ms_total, double *merge_ms_total, int32_t *n_runs);
 /* Total of the descriptor kernel (fast path only) over the same runs. */

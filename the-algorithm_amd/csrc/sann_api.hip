@@ -87,6 +87,7 @@ struct sann_batch {
   bool ran = false;
   // optional HIP-event timing of the kernels, on the stream they are launched on
   bool profiling = false;
+  bool prof_unit_only = false;  // profiling level 1: bracket the dominant (unit) kernel only
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool ev_pending = false;
   double desc_ms_total = 0.0, unit_ms_total = 0.0, merge_ms_total = 0.0;
@@ -581,7 +582,7 @@ int sann_batch_run(sann_batch_t *b, void *hip_stream) {
     int rc = run_general(b, none, st);
     if (rc != SANN_OK) return rc;
   } else {
-    if (b->profiling) HIP_TRY(hipEventRecord(b->ev[0], st));
+    if (b->profiling && !(b->prof_unit_only && b->use_fast)) HIP_TRY(hipEventRecord(b->ev[0], st));
     if (b->use_fast) {
       hipError_t e = launch_desc(b->ix->view(), b->view(), b->n_units, st);
       if (e != hipSuccess) return fail(SANN_EDEVICE, std::string("launch_desc: ") + hipGetErrorString(e));
@@ -596,7 +597,10 @@ int sann_batch_run(sann_batch_t *b, void *hip_stream) {
   }
   if (b->profiling) HIP_TRY(hipEventRecord(b->ev[1], st));
   HIP_TRY(launch_merge(b->ix->view(), b->view(), nullptr, b->nq, st));
-  if (b->profiling) { HIP_TRY(hipEventRecord(b->ev[2], st)); b->ev_pending = true; }
+  if (b->profiling) {
+    if (!b->prof_unit_only) HIP_TRY(hipEventRecord(b->ev[2], st));
+    b->ev_pending = true;
+  }
   HIP_TRY(hipMemcpyAsync(b->h_status, b->status.p, 2 * 4, hipMemcpyDeviceToHost, st));
   b->ran = true;
   return SANN_OK;
@@ -611,11 +615,15 @@ int sann_batch_finish(sann_batch_t *b, void *hip_stream) {
   if (b->nq == 0) return SANN_OK;
   if (b->ev_pending) {
     float a = 0.f, c = 0.f, d = 0.f;
-    HIP_TRY(hipEventElapsedTime(&a, b->ev[0], b->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&c, b->ev[1], b->ev[2]));
-    if (b->use_fast) {
-      HIP_TRY(hipEventElapsedTime(&d, b->ev[0], b->ev[3]));  // descriptor kernel
-      a -= d;
+    if (b->prof_unit_only && b->use_fast) {
+      HIP_TRY(hipEventElapsedTime(&a, b->ev[3], b->ev[1]));  // the unit kernel alone
+    } else {
+      HIP_TRY(hipEventElapsedTime(&a, b->ev[0], b->ev[1]));
+      if (!b->prof_unit_only) HIP_TRY(hipEventElapsedTime(&c, b->ev[1], b->ev[2]));
+      if (b->use_fast) {
+        HIP_TRY(hipEventElapsedTime(&d, b->ev[0], b->ev[3]));  // descriptor kernel
+        a -= d;
+      }
     }
     b->desc_ms_total += d;
     b->unit_ms_total += a;
@@ -723,6 +731,7 @@ int sann_batch_set_profiling(sann_batch_t *b, int32_t enable) {
     for (auto &e : b->ev)
       if (!e) HIP_TRY(hipEventCreate(&e));
   b->profiling = enable != 0;
+  b->prof_unit_only = enable == 1;
   b->desc_ms_total = b->unit_ms_total = b->merge_ms_total = 0.0;
   b->timed_runs = 0;
   b->ev_pending = false;

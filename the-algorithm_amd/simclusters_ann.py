@@ -405,8 +405,10 @@ class QueryBatch:
         _check(load_library().sann_batch_device_k(self._h, C.byref(p)))
         return p.value
 
-    def set_profiling(self, enable: bool = True):
-        _check(load_library().sann_batch_set_profiling(self._h, 1 if enable else 0))
+    def set_profiling(self, enable=True):
+        """False / 0: off; 1: events around the unit kernel only; True / 2: descriptor, unit and merge kernels."""
+        level = 2 if enable is True else int(enable)
+        _check(load_library().sann_batch_set_profiling(self._h, level))
 
     def kernel_times(self):
         """(unit kernel ms total, merge kernel ms total, timed runs) since set_profiling."""
