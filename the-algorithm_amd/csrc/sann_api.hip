@@ -573,8 +573,10 @@ int sann_batch_run(sann_batch_t *b, void *hip_stream) {
   hipStream_t st = (hipStream_t)hip_stream;
   HIP_TRY(hipSetDevice(b->ix->device));
   if (b->nq == 0) { b->ran = true; return SANN_OK; }
-  HIP_TRY(hipMemsetAsync(b->status.p, 0, ((size_t)b->nq + 2) * 4, st));
-  HIP_TRY(hipMemsetAsync(b->unit_fb.p, 0xFF, (size_t)b->n_units * 4, st));
+  if (!b->use_fast) {  // the fast path's descriptor kernel clears these itself
+    HIP_TRY(hipMemsetAsync(b->status.p, 0, ((size_t)b->nq + 2) * 4, st));
+    HIP_TRY(hipMemsetAsync(b->unit_fb.p, 0xFF, (size_t)b->n_units * 4, st));
+  }
   if (!b->use_fast && b->g_cap_units < b->n_units) {
     // all-general mode: size the workspace before the timed launches
     std::vector<int32_t> none;

@@ -94,7 +94,14 @@ hipError_t launch_cut(const IndexView &ix, int M, uint32_t *out, hipStream_t str
 __global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, int n_units) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int unit = blockIdx.x * 4 + wave;
+  // per-run state the unit and merge kernels update: cleared here instead of by two memset launches
+  // (status: overflow count, inexact count, inexact list -- nq + 2 ints; one thread each)
+  {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < b.nq + 2) b.status[g] = 0;
+  }
   if (unit >= n_units) return;
+  if (lane == 0) b.unit_fb[unit] = -1;
   const int q = unit >> ix.log2P;
   const int p = unit & (ix.P - 1);
   const int M = b.hdr[q].M;
