@@ -21,6 +21,7 @@ Prints ONE JSON line on rank 0 (see the task contract) with `roofline` and `cpu_
 """
 import argparse
 import ctypes
+import dataclasses
 import json
 import os
 import sys
@@ -140,105 +141,132 @@ def main():
     # cr-mixer default config with maxNumResults = 400
     cfg = pkg.SimClustersANNConfig(maxNumResults=400, minScore=0.0, maxTopTweetsPerCluster=800, maxScanClusters=50,
                                    maxTweetCandidateAgeHours=24, minTweetCandidateAgeHours=0, annAlgorithm=alg)
-    qb = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=now_ms)
-    stride = qb.stride
-    stream = 0
-
-    # ---- multi-GPU plumbing: per-shard answers -> all-to-all by query owner -> exact merge ----------
-    # Rank r owns queries [r*nql, (r+1)*nql).  Every rank answers all nq queries on its tweet-hash shard;
-    # chunk r of each result array goes to rank r (RCCL all-to-all over xGMI: (world-1)/world of
-    # nq*k*16 B leaves each GPU, the same amount arrives), and the owner merges world per-shard lists.
+    # Sharded runs: a shard holds about K / world of a query's final top-K (tweets are hashed to shards), so it
+    # delivers only its top shard_k = K/world + 6 sigma + 8 -- the per-shard merge, the exchange and the owner's merge
+    # all shrink by K / shard_k -- and the owner PROVES the merged top-K exact from the cut lists
+    # (sann_merge_shards_cut); a batch that cannot be proven is redone with shard_k = K.
+    K = cfg.maxNumResults
+    shard_k = K
     if world > 1:
-        stream = torch.cuda.current_stream().cuda_stream
-        s_ids = torch.zeros(nq * stride, dtype=torch.int64, device="cuda")
-        s_sc = torch.zeros(nq * stride, dtype=torch.int64, device="cuda")  # fp64 bit patterns
-        s_cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
-        s_msz = torch.zeros(nq, dtype=torch.int32, device="cuda")
-        qb.bind_outputs(s_ids.data_ptr(), s_sc.data_ptr(), s_cnt.data_ptr(), s_msz.data_ptr())
-        r_ids, r_sc, r_cnt, r_msz = (torch.zeros_like(t) for t in (s_ids, s_sc, s_cnt, s_msz))  # [world][nql][...]
-        out_ids = torch.zeros((nql, stride), dtype=torch.int64, device="cuda")
-        out_sc = torch.zeros((nql, stride), dtype=torch.float64, device="cuda")
-        out_cnt = torch.zeros(nql, dtype=torch.int32, device="cuda")
-        out_msz = torch.zeros(nql, dtype=torch.int32, device="cuda")
-        d_k = qb.device_k() + rank * nql * 4
+        share = K / world
+        shard_k = min(K, int(-(-(share + 6.0 * (share * (1.0 - 1.0 / world)) ** 0.5 + 8.0) // 8) * 8))
+    inexact_seen = 0
+    while True:
+        cfg_run = cfg if shard_k == K else dataclasses.replace(cfg, maxNumResults=shard_k)
+        qb = pkg.QueryBatch(index, offs, cids, scs, cfg_run, now_ms=now_ms)
+        stride = qb.stride
+        stream = 0
 
-    def exchange(send, recv):
-        if args.backend == "gloo":  # rehearsal: gloo has no all-to-all; gather on the host and slice
-            h = send.cpu()
-            parts = [torch.zeros_like(h) for _ in range(world)]
-            dist.all_gather(parts, h)
-            c = h.numel() // world
-            recv.copy_(torch.cat([p[rank * c:(rank + 1) * c] for p in parts]))
-        else:
-            dist.all_to_all_single(recv, send)
-
-    def step():
-        qb.run(stream)
-        qb.finish(stream)  # waits for the stream; re-runs whatever the fast path flagged, before anything is sent
+        # ---- multi-GPU plumbing: per-shard answers -> all-to-all by query owner -> exact merge ----------
+        # Rank r owns queries [r*nql, (r+1)*nql).  Every rank answers all nq queries on its tweet-hash shard;
+        # chunk r of each result array goes to rank r (RCCL all-to-all over xGMI: (world-1)/world of
+        # nq*k*16 B leaves each GPU, the same amount arrives), and the owner merges world per-shard lists.
         if world > 1:
-            for send, recv in ((s_ids, r_ids), (s_sc, r_sc), (s_cnt, r_cnt), (s_msz, r_msz)):
-                exchange(send, recv)
-            rc = lib.sann_merge_shards(local_rank, ctypes.c_void_p(stream), world, nql, stride, 0, r_ids.data_ptr(),
-                                       r_sc.data_ptr(), r_cnt.data_ptr(), r_msz.data_ptr(),
-                                       d_k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr())
-            assert rc == 0, lib.sann_last_error()
+            stream = torch.cuda.current_stream().cuda_stream
+            s_ids = torch.zeros(nq * stride, dtype=torch.int64, device="cuda")
+            s_sc = torch.zeros(nq * stride, dtype=torch.int64, device="cuda")  # fp64 bit patterns
+            s_cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+            s_msz = torch.zeros(nq, dtype=torch.int32, device="cuda")
+            qb.bind_outputs(s_ids.data_ptr(), s_sc.data_ptr(), s_cnt.data_ptr(), s_msz.data_ptr())
+            r_ids, r_sc, r_cnt, r_msz = (torch.zeros_like(t) for t in (s_ids, s_sc, s_cnt, s_msz))  # [world][nql][...]
+            out_ids = torch.zeros((nql, K), dtype=torch.int64, device="cuda")
+            out_sc = torch.zeros((nql, K), dtype=torch.float64, device="cuda")
+            out_cnt = torch.zeros(nql, dtype=torch.int32, device="cuda")
+            out_msz = torch.zeros(nql, dtype=torch.int32, device="cuda")
+            d_k = qb.device_k() + rank * nql * 4
+            d_bad = torch.zeros(1, dtype=torch.int32, device="cuda")  # queries whose cut per-shard lists could not prove the merge exact
 
-    def sync():
+        def exchange(send, recv):
+            if args.backend == "gloo":  # rehearsal: gloo has no all-to-all; gather on the host and slice
+                h = send.cpu()
+                parts = [torch.zeros_like(h) for _ in range(world)]
+                dist.all_gather(parts, h)
+                c = h.numel() // world
+                recv.copy_(torch.cat([p[rank * c:(rank + 1) * c] for p in parts]))
+            else:
+                dist.all_to_all_single(recv, send)
+
+        def step():
+            qb.run(stream)
+            qb.finish(stream)  # waits for the stream; re-runs whatever the fast path flagged, before anything is sent
+            if world > 1:
+                for send, recv in ((s_ids, r_ids), (s_sc, r_sc), (s_cnt, r_cnt), (s_msz, r_msz)):
+                    exchange(send, recv)
+                if shard_k < K:
+                    rc = lib.sann_merge_shards_cut(local_rank, ctypes.c_void_p(stream), world, nql, stride, shard_k, K, K,
+                                                   r_ids.data_ptr(), r_sc.data_ptr(), r_cnt.data_ptr(), r_msz.data_ptr(),
+                                                   out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr(),
+                                                   d_bad.data_ptr())
+                else:
+                    rc = lib.sann_merge_shards(local_rank, ctypes.c_void_p(stream), world, nql, stride, 0, r_ids.data_ptr(),
+                                               r_sc.data_ptr(), r_cnt.data_ptr(), r_msz.data_ptr(),
+                                               d_k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr())
+                assert rc == 0, lib.sann_last_error()
+
+        def sync():
+            if world > 1:
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+            else:
+                assert lib.sann_device_synchronize(local_rank) == 0
+
+        def check_sharded_against_unsharded():
+            """Rehearsal only: rank 0 also builds the whole corpus and checks the merged answer of its queries."""
+            full = pkg.ClusterTweetIndex.synthetic(args.tweets, pkg.corpus.N_CLUSTERS, seed=pkg.corpus.CORPUS_SEED,
+                                                   index_cap=2000, now_ms=now_ms, device=local_rank, n_partitions=args.partitions)
+            qf = pkg.QueryBatch(full, offs[:nql + 1], cids[:offs[nql]], scs[:offs[nql]], cfg, now_ms=now_ms)
+            qf.run(); qf.finish()
+            f_ids, f_sc, f_cnt, f_msz = qf.results()
+            qf.close(); full.close()
+            return bool(np.array_equal(f_cnt, counts) and np.array_equal(f_msz, msz) and np.array_equal(f_ids, ids)
+                        and np.array_equal(f_sc.view(np.int64), scores.view(np.int64)))
+
+        for _ in range(args.warmup):
+            step()
+        # the timed region carries HIP events around the dominant kernel only (two per step; each event costs the
+        # stream ~5 us); the descriptor and merge kernels are timed over a few extra steps afterwards
+        qb.set_profiling(1)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        unit_ms, _m, n_timed = qb.kernel_times()
+        qb.set_profiling(2)
+        n_aux = max(3, min(10, args.steps))
+        for _ in range(n_aux):
+            step()
+        sync()
+        _u, merge_ms, _n = qb.kernel_times()
+        desc_ms = qb.desc_time()
+        merge_ms, desc_ms = merge_ms * n_timed / n_aux, desc_ms * n_timed / n_aux  # reported as per-launch averages below
+        qb.set_profiling(False)
+        # ---- results of the last step (this rank's own queries when sharded) -----------------------
         if world > 1:
             torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+            ids, scores, counts, msz = out_ids.cpu().numpy(), out_sc.cpu().numpy(), out_cnt.cpu().numpy(), out_msz.cpu().numpy()
         else:
-            assert lib.sann_device_synchronize(local_rank) == 0
-
-    def check_sharded_against_unsharded():
-        """Rehearsal only: rank 0 also builds the whole corpus and checks the merged answer of its queries."""
-        full = pkg.ClusterTweetIndex.synthetic(args.tweets, pkg.corpus.N_CLUSTERS, seed=pkg.corpus.CORPUS_SEED,
-                                               index_cap=2000, now_ms=now_ms, device=local_rank, n_partitions=args.partitions)
-        qf = pkg.QueryBatch(full, offs[:nql + 1], cids[:offs[nql]], scs[:offs[nql]], cfg, now_ms=now_ms)
-        qf.run(); qf.finish()
-        f_ids, f_sc, f_cnt, f_msz = qf.results()
-        qf.close(); full.close()
-        return bool(np.array_equal(f_cnt, counts) and np.array_equal(f_msz, msz) and np.array_equal(f_ids, ids)
-                    and np.array_equal(f_sc.view(np.int64), scores.view(np.int64)))
-
-    for _ in range(args.warmup):
-        step()
-    # the timed region carries HIP events around the dominant kernel only (two per step; each event costs the
-    # stream ~5 us); the descriptor and merge kernels are timed over a few extra steps afterwards
-    qb.set_profiling(1)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    unit_ms, _m, n_timed = qb.kernel_times()
-    qb.set_profiling(2)
-    n_aux = max(3, min(10, args.steps))
-    for _ in range(n_aux):
-        step()
-    sync()
-    _u, merge_ms, _n = qb.kernel_times()
-    desc_ms = qb.desc_time()
-    merge_ms, desc_ms = merge_ms * n_timed / n_aux, desc_ms * n_timed / n_aux  # reported as per-launch averages below
-    qb.set_profiling(False)
-    # ---- results of the last step (this rank's own queries when sharded) -----------------------
-    if world > 1:
-        torch.cuda.synchronize()
-        ids, scores, counts, msz = out_ids.cpu().numpy(), out_sc.cpu().numpy(), out_cnt.cpu().numpy(), out_msz.cpu().numpy()
-    else:
-        ids, scores, counts, msz = qb.results()
-    st = qb.stats()
-    candidates_per_step = int(counts.sum())
-    if world > 1:
-        dev = "cpu" if args.backend == "gloo" else "cuda"
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        tc = torch.tensor([candidates_per_step], dtype=torch.int64, device=dev)
-        dist.all_reduce(tc, op=dist.ReduceOp.SUM)
-        candidates_per_step = int(tc.item())  # whole job: every rank's queries
+            ids, scores, counts, msz = qb.results()
+        st = qb.stats()
+        candidates_per_step = int(counts.sum())
+        if world > 1:
+            dev = "cpu" if args.backend == "gloo" else "cuda"
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            tc = torch.tensor([candidates_per_step, int(d_bad.item())], dtype=torch.int64, device=dev)
+            dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+            candidates_per_step = int(tc[0].item())  # whole job: every rank's queries
+            if int(tc[1].item()) > 0 and shard_k < K:
+                # some query's merged top-k could not be proven exact from the cut lists: the whole measurement
+                # is repeated with full-length per-shard lists (expected never; the proof is checked every batch)
+                inexact_seen += int(tc[1].item())
+                shard_k = K
+                qb.close()
+                continue
+        break
     value = candidates_per_step * args.steps / elapsed
 
     if rank != 0:
@@ -321,6 +349,7 @@ def main():
                    "queries": nq, "tweets": args.tweets, "clusters": 144428, "k": 400, "max_scan_clusters": 50,
                    "max_top_tweets_per_cluster": 800, "algorithm": args.alg, "index_cap": 2000,
                    "partitions": index.info().n_partitions, "sharding": "none" if world == 1 else "tweet-hash",
+                   "shard_list_length": shard_k, "queries_not_proven_by_cut_lists": inexact_seen,
                    "corpus": args.corpus, "index_postings": int(index.info().n_postings_total)},
         "queries_per_sec": nq * args.steps / elapsed,
         "postings_per_sec": int(st.postings_scanned) * args.steps / elapsed,

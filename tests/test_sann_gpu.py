@@ -247,6 +247,79 @@ def test_tweet_hash_shards_merge_exactly(pkg, oracle, small):
         qb.close(); ix.close()
 
 
+def test_cut_shard_lists_merge_exactly_or_say_so(pkg, oracle, small):
+    """sann_merge_shards_cut: every shard delivers only its top shard_k; the owner's merged top-k equals the
+    unsharded answer whenever the kernel's proof holds (no cut list ends above the merged k-th key), and the
+    queries where it does not hold are counted -- the count must match the same rule evaluated on the host."""
+    import ctypes as C
+    import torch
+
+    co, offs, cids, scs = small
+    K, S = 120, 3
+    cfg = pkg.SimClustersANNConfig(maxNumResults=K, maxTopTweetsPerCluster=300)
+    nq = len(offs) - 1
+    dev = torch.device("cuda:0")
+    hip = C.CDLL("libamdhip64.so")
+    lib = pkg.load_library()
+    shards = [pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=8, shard_id=s,
+                                    n_shards=S) for s in range(S)]
+    seen_exact = seen_inexact = False
+    for shard_k in (K, 72, 56, 8):
+        cfg_s = pkg.SimClustersANNConfig(maxNumResults=shard_k, maxTopTweetsPerCluster=300)
+        g_ids = torch.zeros((S, nq, shard_k), dtype=torch.int64, device=dev)
+        g_sc = torch.zeros((S, nq, shard_k), dtype=torch.float64, device=dev)
+        g_cnt = torch.zeros((S, nq), dtype=torch.int32, device=dev)
+        g_msz = torch.zeros((S, nq), dtype=torch.int32, device=dev)
+        for s, ix in enumerate(shards):
+            qb = pkg.QueryBatch(ix, offs, cids, scs, cfg_s, now_ms=co.now_ms)
+            qb.run(); qb.finish()
+            (p_ids, p_sc, p_cnt, p_msz), st = qb.device_results()
+            assert st == shard_k
+            for dst, src, nbytes in ((g_ids[s], p_ids, nq * st * 8), (g_sc[s], p_sc, nq * st * 8),
+                                     (g_cnt[s], p_cnt, nq * 4), (g_msz[s], p_msz, nq * 4)):
+                assert hip.hipMemcpy(C.c_void_p(dst.data_ptr()), C.c_void_p(src), C.c_size_t(nbytes), 3) == 0
+            qb.close()
+        o_ids = torch.zeros((nq, K), dtype=torch.int64, device=dev)
+        o_sc = torch.zeros((nq, K), dtype=torch.float64, device=dev)
+        o_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+        o_msz = torch.zeros(nq, dtype=torch.int32, device=dev)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        rc = lib.sann_merge_shards_cut(0, None, S, nq, shard_k, shard_k, K, K, g_ids.data_ptr(), g_sc.data_ptr(),
+                                       g_cnt.data_ptr(), g_msz.data_ptr(), o_ids.data_ptr(), o_sc.data_ptr(),
+                                       o_cnt.data_ptr(), o_msz.data_ptr(), bad.data_ptr())
+        assert rc == 0, lib.sann_last_error()
+        torch.cuda.synchronize()
+        # the same rule on the host
+        h_ids, h_sc, h_cnt = g_ids.cpu().numpy(), g_sc.cpu().numpy(), g_cnt.cpu().numpy()
+        flagged = np.zeros(nq, bool)
+        for q in range(nq):
+            ent = sorted((-float(h_sc[s, q, j]), int(h_ids[s, q, j])) for s in range(S) for j in range(h_cnt[s, q]))
+            kth = ent[K - 1] if len(ent) >= K else None
+            for s in range(S):
+                c = h_cnt[s, q]
+                if c >= shard_k:
+                    last = (-float(h_sc[s, q, c - 1]), int(h_ids[s, q, c - 1]))
+                    if kth is None or last < kth:
+                        flagged[q] = True
+        assert int(bad.item()) == int(flagged.sum()), (shard_k, int(bad.item()), int(flagged.sum()))
+        out = (o_ids.cpu().numpy(), o_sc.cpu().numpy(), o_cnt.cpu().numpy(), o_msz.cpu().numpy())
+        keep = np.flatnonzero(~flagged)
+        seen_exact |= shard_k < K and len(keep) == nq
+        seen_inexact |= bool(flagged.any())
+        # every query the proof covers equals the unsharded oracle answer, bit for bit
+        for q in keep:
+            e_ids, e_sc, e_msz = oracle.sann_query(cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]], None, cfg, co.now_ms,
+                                                   co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores)
+            n = out[2][q]
+            assert n == len(e_ids) and out[3][q] == e_msz, (shard_k, q)
+            assert np.array_equal(out[0][q, :n], e_ids) and np.array_equal(out[1][q, :n].view(np.int64), e_sc.view(np.int64))
+        if shard_k == K:
+            assert not flagged.any()  # full-length lists can never be flagged
+    assert seen_exact and seen_inexact  # the sweep exercised both outcomes
+    for ix in shards:
+        ix.close()
+
+
 def test_device_fp64_division_sqrt_log_are_bit_exact(pkg, oracle):
     """The normalisation (ApproximateCosineSimilarity.scala:111-119) evaluated on the device equals
     the host's IEEE result bit for bit: correctly rounded / and sqrt, and the fdlibm log."""

@@ -861,9 +861,28 @@ int sann_merge_shards(int32_t device, void *hip_stream, int32_t n_shards, int32_
   HIP_TRY(hipSetDevice(device));
   if (shard_pitch_bytes < 0 || (shard_pitch_bytes & 7)) return fail(SANN_EINVAL, "shard_pitch_bytes must be a non-negative multiple of 8");
   HIP_TRY(launch_merge_shards(n_shards, nq, stride, shard_pitch_bytes, (const int64_t *)d_ids, (const double *)d_scores,
-                              (const int32_t *)d_counts, (const int32_t *)d_map_sizes, (const int32_t *)d_k,
+                              (const int32_t *)d_counts, (const int32_t *)d_map_sizes, (const int32_t *)d_k, 0, 0, stride,
                               (int64_t *)d_out_ids, (double *)d_out_scores, (int32_t *)d_out_counts,
-                              (int32_t *)d_out_map_sizes, (hipStream_t)hip_stream));
+                              (int32_t *)d_out_map_sizes, nullptr, (hipStream_t)hip_stream));
+  return SANN_OK;
+}
+
+int sann_merge_shards_cut(int32_t device, void *hip_stream, int32_t n_shards, int32_t nq, int32_t shard_stride,
+                          int32_t shard_k, int32_t k, int32_t out_stride, const void *d_ids, const void *d_scores,
+                          const void *d_counts, const void *d_map_sizes, void *d_out_ids, void *d_out_scores,
+                          void *d_out_counts, void *d_out_map_sizes, void *d_inexact_count) {
+  if (n_shards < 1 || nq < 0 || shard_stride < 1 || shard_stride > 1024 || out_stride < 1 || out_stride > 1024)
+    return fail(SANN_EINVAL, "bad merge sizes");
+  if (shard_k < 1 || shard_k > shard_stride || k < 0) return fail(SANN_EINVAL, "bad shard_k / k");
+  if (nq == 0) return SANN_OK;
+  if (!d_ids || !d_scores || !d_counts || !d_map_sizes || !d_out_ids || !d_out_scores || !d_out_counts || !d_out_map_sizes ||
+      !d_inexact_count)
+    return fail(SANN_EINVAL, "NULL device pointer");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(launch_merge_shards(n_shards, nq, shard_stride, 0, (const int64_t *)d_ids, (const double *)d_scores,
+                              (const int32_t *)d_counts, (const int32_t *)d_map_sizes, nullptr, k, shard_k, out_stride,
+                              (int64_t *)d_out_ids, (double *)d_out_scores, (int32_t *)d_out_counts,
+                              (int32_t *)d_out_map_sizes, (int32_t *)d_inexact_count, (hipStream_t)hip_stream));
   return SANN_OK;
 }
 

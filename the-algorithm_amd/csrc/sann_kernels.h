@@ -10,9 +10,10 @@ hipError_t launch_unit_general(const IndexView &ix, const BatchView &b, const Ge
                                hipStream_t stream);
 hipError_t launch_merge(const IndexView &ix, const BatchView &b, const int32_t *query_list, int n_queries,
                         hipStream_t stream);
-hipError_t launch_merge_shards(int n_shards, int nq, int stride, int64_t shard_pitch_bytes, const int64_t *ids, const double *scores,
-                               const int32_t *counts, const int32_t *map_sizes, const int32_t *k, int64_t *out_ids,
-                               double *out_scores, int32_t *out_counts, int32_t *out_map_sizes, hipStream_t stream);
+hipError_t launch_merge_shards(int n_shards, int nq, int stride, int64_t pitch, const int64_t *ids, const double *scores,
+                               const int32_t *counts, const int32_t *map_sizes, const int32_t *k, int k_all, int shard_k,
+                               int out_stride, int64_t *out_ids, double *out_scores, int32_t *out_counts,
+                               int32_t *out_map_sizes, int32_t *inexact, hipStream_t stream);
 
 hipError_t launch_debug_normalise(int alg, int n, const double *dot, const double *nsq, double l2norm, double lognorm,
                                   double *out, hipStream_t stream);

@@ -623,11 +623,15 @@ struct ShardSrc {
   }
 };
 
+// shard_k > 0: every shard list was cut at shard_k entries (sorted, so its last entry is its smallest).  The
+// merged top-k is then exact iff no cut list could hide a better candidate, i.e. every list with shard_k
+// entries ends at or below the merged k-th key; otherwise the query is counted in *inexact.
 __global__ __launch_bounds__(WG) void merge_shards_kernel(int n_shards, int nq, int stride, int64_t pitch,
                                                          const int64_t *ids, const double *scores,
                                                          const int32_t *counts, const int32_t *map_sizes,
-                                                         const int32_t *k, int64_t *out_ids, double *out_scores,
-                                                         int32_t *out_counts, int32_t *out_map_sizes) {
+                                                         const int32_t *k, int k_all, int shard_k, int out_stride,
+                                                         int64_t *out_ids, double *out_scores,
+                                                         int32_t *out_counts, int32_t *out_map_sizes, int32_t *inexact) {
   __shared__ uint64_t s_hi[KMAX], s_lo[KMAX];
   __shared__ unsigned s_hist[256];
   __shared__ int s_ctl[4];
@@ -636,14 +640,26 @@ __global__ __launch_bounds__(WG) void merge_shards_kernel(int n_shards, int nq, 
   const int64_t pitch_ids = pitch ? pitch : (int64_t)nq * stride * 8;
   const int64_t pitch_cnt = pitch ? pitch : (int64_t)nq * 4;
   ShardSrc src{ids, scores, counts, n_shards, nq, stride, q, pitch_ids, pitch_cnt};
-  int kk = k[q] < stride ? k[q] : stride;
+  int kk = k ? k[q] : k_all;
+  kk = kk < out_stride ? kk : out_stride;
   uint64_t xh, xl;
-  merge_select_sort_write(src, kk, out_ids + (int64_t)q * stride, out_scores + (int64_t)q * stride, out_counts + q,
+  merge_select_sort_write(src, kk, out_ids + (int64_t)q * out_stride, out_scores + (int64_t)q * out_stride, out_counts + q,
                           s_hi, s_lo, s_hist, s_ctl, &s_cnt, xh, xl);
   if (threadIdx.x == 0) {
-    int m = 0;
-    for (int s = 0; s < n_shards; s++) m += ((const int32_t *)((const char *)map_sizes + s * pitch_cnt))[q];
+    int m = 0, bad = 0;
+    for (int s = 0; s < n_shards; s++) {
+      m += ((const int32_t *)((const char *)map_sizes + s * pitch_cnt))[q];
+      const int c = ((const int32_t *)((const char *)counts + s * pitch_cnt))[q];
+      if (shard_k > 0 && c >= shard_k && kk > 0) {
+        // the list was (possibly) cut: its smallest delivered key against the merged k-th key (0,0 = fewer than k merged)
+        const int64_t o = (int64_t)q * stride + c - 1;
+        const uint64_t lh = score_key(((const double *)((const char *)scores + s * pitch_ids))[o]);
+        const uint64_t ll = id_key(((const int64_t *)((const char *)ids + s * pitch_ids))[o]);
+        if (key_gt(lh, ll, xh, xl)) bad = 1;
+      }
+    }
     out_map_sizes[q] = m;
+    if (bad && inexact) atomicAdd(inexact, 1);
   }
 }
 
@@ -680,11 +696,12 @@ hipError_t launch_merge(const IndexView &ix, const BatchView &b, const int32_t *
   return hipGetLastError();
 }
 hipError_t launch_merge_shards(int n_shards, int nq, int stride, int64_t pitch, const int64_t *ids, const double *scores,
-                               const int32_t *counts, const int32_t *map_sizes, const int32_t *k, int64_t *out_ids,
-                               double *out_scores, int32_t *out_counts, int32_t *out_map_sizes, hipStream_t stream) {
+                               const int32_t *counts, const int32_t *map_sizes, const int32_t *k, int k_all, int shard_k,
+                               int out_stride, int64_t *out_ids, double *out_scores, int32_t *out_counts,
+                               int32_t *out_map_sizes, int32_t *inexact, hipStream_t stream) {
   if (nq <= 0) return hipSuccess;
   hipLaunchKernelGGL(merge_shards_kernel, dim3(nq), dim3(WG), 0, stream, n_shards, nq, stride, pitch, ids, scores, counts,
-                     map_sizes, k, out_ids, out_scores, out_counts, out_map_sizes);
+                     map_sizes, k, k_all, shard_k, out_stride, out_ids, out_scores, out_counts, out_map_sizes, inexact);
   return hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
 """What one GPU of an N-GPU run does per step, measured on one GPU: shard 0 of N, 1024*N queries, partitions 32/N.
-Prints the step time and the descriptor / unit / per-shard-merge kernel times.  usage: shard_cost.py N [P [tweets]]"""
+Prints the step time and the descriptor / unit / per-shard-merge kernel times.  usage: shard_cost.py N [P [tweets [k]]]  (k = per-shard list length, default 400)"""
 import os
 import sys
 
@@ -13,10 +13,11 @@ import time
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 P = int(sys.argv[2]) if len(sys.argv) > 2 else max(1, 32 // N)
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000_000
+K = int(sys.argv[4]) if len(sys.argv) > 4 else 400
 nq = 1024 * N
 offs, cids, scs = pkg.corpus.make_queries(nq)
 index = pkg.ClusterTweetIndex.synthetic(T, n_partitions=P, shard_id=0, n_shards=N)
-cfg = pkg.SimClustersANNConfig(maxNumResults=400, annAlgorithm=pkg.ScoringAlgorithm.CosineSimilarity)
+cfg = pkg.SimClustersANNConfig(maxNumResults=K, annAlgorithm=pkg.ScoringAlgorithm.CosineSimilarity)
 qb = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=pkg.corpus.NOW_MS)
 for _once in (0,):
     for _ in range(3):
@@ -31,5 +32,5 @@ for _once in (0,):
     d = qb.desc_time()
     qb.set_profiling(False)
     st = qb.stats()
-    print(f"N={N} P={P}: step {wall * 1e3:.3f} ms, fallback/step {(st.n_fallback_units - fb0) / 10:.0f}, desc {d / n * 1e3:.0f} us, unit {u / n * 1e3:.0f} us, merge {m / n * 1e3:.0f} us, "
+    print(f"N={N} P={P} k={K}: step {wall * 1e3:.3f} ms, fallback/step {(st.n_fallback_units - fb0) / 10:.0f}, desc {d / n * 1e3:.0f} us, unit {u / n * 1e3:.0f} us, merge {m / n * 1e3:.0f} us, "
           f"fallback units {st.n_fallback_units}, units {st.n_units}")
