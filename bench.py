@@ -12,8 +12,9 @@ ApproximateCosineSimilarity.scala:57-128) for every query of the batch.
 
 N = 1   workload = BASELINE.json configs[2]: 1024 concurrent user queries, one GPU.
 N > 1   the corpus is tweet-hash sharded over the N ranks (one process per GPU); every rank
-        answers the whole batch (1024*N queries) on its shard, per-shard top-k lists are
-        all-gathered over RCCL and merged exactly on every rank (ComposedQueryable pattern,
+        answers the whole batch (1024*N queries) on its shard; each query has an owner rank, the
+        per-shard lists (cut at k/N + 6 sigma + 8 entries) reach the owners in one RCCL all-to-all
+        and the owner merges them exactly, proving the cut harmless (ComposedQueryable pattern,
         reference ann/.../common/ShardApi.scala:71-87).  Per-GPU posting work is constant in N:
         "scaling": "weak".
 
@@ -67,6 +68,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU path); gloo = host-staged exchange, only to "
                          "rehearse the N > 1 code path with several ranks sharing one GPU")
+    ap.add_argument("--exercise-exchange", action="store_true",
+                    help="N = 1 only: run the sharded path (process group, all-to-all, owner merge) with one shard")
+    ap.add_argument("--shard-k", type=int, default=0, help="override the per-shard list length of sharded runs (0 = k/N + 6 sigma + 8)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cpu_count, 16))")
     args = ap.parse_args()
     if args.workload != "sann":
@@ -82,8 +86,13 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
 
+    # --exercise-exchange: a 1-GPU run that still goes through process-group init, the all-to-all and the owner's
+    # merge (one shard), so the RCCL plumbing of the N > 1 path can be checked on a 1-GPU box
+    sharded = world > 1 or args.exercise_exchange
     dist = torch = None
-    if world > 1:
+    if sharded:
+        for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(key, val)
         import torch
         import torch.distributed as dist
 
@@ -150,6 +159,8 @@ def main():
     if world > 1:
         share = K / world
         shard_k = min(K, int(-(-(share + 6.0 * (share * (1.0 - 1.0 / world)) ** 0.5 + 8.0) // 8) * 8))
+    if args.shard_k > 0 and sharded:
+        shard_k = min(K, args.shard_k)
     inexact_seen = 0
     while True:
         cfg_run = cfg if shard_k == K else dataclasses.replace(cfg, maxNumResults=shard_k)
@@ -159,16 +170,18 @@ def main():
 
         # ---- multi-GPU plumbing: per-shard answers -> all-to-all by query owner -> exact merge ----------
         # Rank r owns queries [r*nql, (r+1)*nql).  Every rank answers all nq queries on its tweet-hash shard;
-        # chunk r of each result array goes to rank r (RCCL all-to-all over xGMI: (world-1)/world of
-        # nq*k*16 B leaves each GPU, the same amount arrives), and the owner merges world per-shard lists.
-        if world > 1:
+        # the merge kernel writes query q's results straight into the message of its owner, and ONE all-to-all
+        # (RCCL over xGMI: (world-1)/world of nq*shard_k*16 B leaves each GPU, the same amount arrives) delivers
+        # them; the owner merges world per-shard lists.
+        if sharded:
             stream = torch.cuda.current_stream().cuda_stream
-            s_ids = torch.zeros(nq * stride, dtype=torch.int64, device="cuda")
-            s_sc = torch.zeros(nq * stride, dtype=torch.int64, device="cuda")  # fp64 bit patterns
-            s_cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
-            s_msz = torch.zeros(nq, dtype=torch.int32, device="cuda")
-            qb.bind_outputs(s_ids.data_ptr(), s_sc.data_ptr(), s_cnt.data_ptr(), s_msz.data_ptr())
-            r_ids, r_sc, r_cnt, r_msz = (torch.zeros_like(t) for t in (s_ids, s_sc, s_cnt, s_msz))  # [world][nql][...]
+            # one packed message per owner: [ids nql*stride | score bits nql*stride | counts nql | map sizes nql]
+            arr = nql * stride * 8
+            chunk = 2 * arr + 8 * nql  # bytes, a multiple of 8
+            send = torch.zeros(world * chunk, dtype=torch.uint8, device="cuda")
+            recv = torch.zeros_like(send)  # [world shards][chunk]: this rank's queries, one chunk per shard
+            sp, rp = send.data_ptr(), recv.data_ptr()
+            qb.bind_outputs_chunked(sp, sp + arr, sp + 2 * arr, sp + 2 * arr + 4 * nql, nql, chunk)
             out_ids = torch.zeros((nql, K), dtype=torch.int64, device="cuda")
             out_sc = torch.zeros((nql, K), dtype=torch.float64, device="cuda")
             out_cnt = torch.zeros(nql, dtype=torch.int32, device="cuda")
@@ -189,22 +202,21 @@ def main():
         def step():
             qb.run(stream)
             qb.finish(stream)  # waits for the stream; re-runs whatever the fast path flagged, before anything is sent
-            if world > 1:
-                for send, recv in ((s_ids, r_ids), (s_sc, r_sc), (s_cnt, r_cnt), (s_msz, r_msz)):
-                    exchange(send, recv)
+            if sharded:
+                exchange(send, recv)
                 if shard_k < K:
-                    rc = lib.sann_merge_shards_cut(local_rank, ctypes.c_void_p(stream), world, nql, stride, shard_k, K, K,
-                                                   r_ids.data_ptr(), r_sc.data_ptr(), r_cnt.data_ptr(), r_msz.data_ptr(),
+                    rc = lib.sann_merge_shards_cut(local_rank, ctypes.c_void_p(stream), world, nql, stride, chunk, shard_k, K, K,
+                                                   rp, rp + arr, rp + 2 * arr, rp + 2 * arr + 4 * nql,
                                                    out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr(),
                                                    d_bad.data_ptr())
                 else:
-                    rc = lib.sann_merge_shards(local_rank, ctypes.c_void_p(stream), world, nql, stride, 0, r_ids.data_ptr(),
-                                               r_sc.data_ptr(), r_cnt.data_ptr(), r_msz.data_ptr(),
+                    rc = lib.sann_merge_shards(local_rank, ctypes.c_void_p(stream), world, nql, stride, chunk, rp, rp + arr,
+                                               rp + 2 * arr, rp + 2 * arr + 4 * nql,
                                                d_k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr())
                 assert rc == 0, lib.sann_last_error()
 
         def sync():
-            if world > 1:
+            if sharded:
                 torch.cuda.synchronize()
                 dist.barrier()
                 torch.cuda.synchronize()
@@ -244,14 +256,14 @@ def main():
         merge_ms, desc_ms = merge_ms * n_timed / n_aux, desc_ms * n_timed / n_aux  # reported as per-launch averages below
         qb.set_profiling(False)
         # ---- results of the last step (this rank's own queries when sharded) -----------------------
-        if world > 1:
+        if sharded:
             torch.cuda.synchronize()
             ids, scores, counts, msz = out_ids.cpu().numpy(), out_sc.cpu().numpy(), out_cnt.cpu().numpy(), out_msz.cpu().numpy()
         else:
             ids, scores, counts, msz = qb.results()
         st = qb.stats()
         candidates_per_step = int(counts.sum())
-        if world > 1:
+        if sharded:
             dev = "cpu" if args.backend == "gloo" else "cuda"
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -270,7 +282,7 @@ def main():
     value = candidates_per_step * args.steps / elapsed
 
     if rank != 0:
-        if world > 1:
+        if sharded:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -364,7 +376,7 @@ def main():
         "corpus_build_s": t_corpus,
     }
     print(json.dumps(line))
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -253,21 +253,31 @@ int sann_merge_shards(int32_t device, void *hip_stream, int32_t n_shards, int32_
 
 /* The same merge when every shard delivers only its top shard_k (< k) -- what makes an N-way sharded run cheap:
  * a shard holds ~k/N of a query's final top-k, so shard_k = k/N + 6 sigma + 8 entries are enough except with
- * vanishing probability, and both the per-shard merges and the exchange shrink by k / shard_k.  Inputs tightly
- * packed shard-major, d_ids[n_shards][nq][shard_stride] (sorted, as sann_batch_run leaves them); one k for all
- * queries; outputs with stride out_stride.  Exactness is checked, not assumed: a query is exact iff every list
+ * vanishing probability, and both the per-shard merges and the exchange shrink by k / shard_k.  Inputs as for
+ * sann_merge_shards (shard_pitch_bytes 0 = d_ids[n_shards][nq][shard_stride] tightly packed; lists sorted, as
+ * sann_batch_run leaves them); one k for all queries; outputs with stride out_stride.  Exactness is checked, not assumed: a query is exact iff every list
  * that came in full (count >= shard_k) ends at or below the merged k-th key; *d_inexact_count (device int32, not
  * reset here) is incremented per query that fails, and the caller then repeats the batch with shard_k = k. */
 int sann_merge_shards_cut(int32_t device, void *hip_stream, int32_t n_shards, int32_t nq, int32_t shard_stride,
-                          int32_t shard_k, int32_t k, int32_t out_stride, const void *d_ids, const void *d_scores,
-                          const void *d_counts, const void *d_map_sizes, void *d_out_ids, void *d_out_scores,
-                          void *d_out_counts, void *d_out_map_sizes, void *d_inexact_count);
+                          int64_t shard_pitch_bytes, int32_t shard_k, int32_t k, int32_t out_stride, const void *d_ids,
+                          const void *d_scores, const void *d_counts, const void *d_map_sizes, void *d_out_ids,
+                          void *d_out_scores, void *d_out_counts, void *d_out_map_sizes, void *d_inexact_count);
 
 /* Make the merge kernel write the final results into caller-owned device buffers (e.g. torch
  * tensors that feed an all-gather) instead of the batch's own; pass four NULLs to unbind.
  * Sizes: int64[nq*stride], double[nq*stride], int32[nq], int32[nq], stride as reported by
  * sann_batch_device_results. */
 int sann_batch_bind_outputs(sann_batch_t *batch, void *d_ids, void *d_scores, void *d_counts, void *d_map_sizes);
+
+/* The same, for results that leave in one all-to-all: query q is written into chunk q / queries_per_chunk (the
+ * chunk of its owner), chunk_pitch_bytes after the previous chunk, at position q % queries_per_chunk of that
+ * chunk's arrays (ids / scores with the batch's stride, counts, map sizes).  Pointing the four bases into one
+ * buffer -- ids at 0, scores after queries_per_chunk*stride*8 bytes, counts after twice that, map sizes
+ * queries_per_chunk*4 bytes later, pitch = the sum -- makes each chunk one contiguous message, and the received
+ * buffer is what sann_merge_shards / sann_merge_shards_cut read with shard_pitch_bytes = the same pitch.
+ * sann_batch_results / sann_batch_device_results refuse a batch bound this way. */
+int sann_batch_bind_outputs_chunked(sann_batch_t *batch, void *d_ids, void *d_scores, void *d_counts, void *d_map_sizes,
+                                    int32_t queries_per_chunk, int64_t chunk_pitch_bytes);
 
 /* Device pointer to int32[nq] holding min(max(maxNumResults,0),1000) per query. */
 int sann_batch_device_k(sann_batch_t *batch, void **d_k);

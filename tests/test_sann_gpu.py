@@ -284,7 +284,7 @@ def test_cut_shard_lists_merge_exactly_or_say_so(pkg, oracle, small):
         o_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
         o_msz = torch.zeros(nq, dtype=torch.int32, device=dev)
         bad = torch.zeros(1, dtype=torch.int32, device=dev)
-        rc = lib.sann_merge_shards_cut(0, None, S, nq, shard_k, shard_k, K, K, g_ids.data_ptr(), g_sc.data_ptr(),
+        rc = lib.sann_merge_shards_cut(0, None, S, nq, shard_k, 0, shard_k, K, K, g_ids.data_ptr(), g_sc.data_ptr(),
                                        g_cnt.data_ptr(), g_msz.data_ptr(), o_ids.data_ptr(), o_sc.data_ptr(),
                                        o_cnt.data_ptr(), o_msz.data_ptr(), bad.data_ptr())
         assert rc == 0, lib.sann_last_error()
@@ -318,6 +318,48 @@ def test_cut_shard_lists_merge_exactly_or_say_so(pkg, oracle, small):
     assert seen_exact and seen_inexact  # the sweep exercised both outcomes
     for ix in shards:
         ix.close()
+
+
+def test_outputs_bound_in_owner_chunks(pkg, small):
+    """sann_batch_bind_outputs_chunked: query q's results land in chunk q // nql of one packed buffer (the message
+    to its owner), identical to the batch's own outputs; a batch bound this way refuses sann_batch_results."""
+    import torch
+
+    co, offs, cids, scs = small
+    cfg = pkg.SimClustersANNConfig(maxNumResults=50, maxTopTweetsPerCluster=300)
+    nq = len(offs) - 1
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=8)
+    qb = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=co.now_ms)
+    qb.run(); qb.finish()
+    ids, sc, cnt, msz = qb.results()
+    stride = qb.stride
+    for nql in (nq // 3, 5, nq):  # 5 does not divide 24: the last chunk is ragged
+        n_chunks = -(-nq // nql)
+        arr = nql * stride * 8
+        chunk = 2 * arr + 8 * nql + 64  # slack between chunks must stay untouched
+        buf = torch.full((n_chunks * chunk,), 0xAB, dtype=torch.uint8, device="cuda:0")
+        p = buf.data_ptr()
+        qb.bind_outputs_chunked(p, p + arr, p + 2 * arr, p + 2 * arr + 4 * nql, nql, chunk)
+        qb.run(); qb.finish()
+        with pytest.raises(pkg.SannError):
+            qb.results()
+        h = buf.cpu().numpy()
+        for q in range(nq):
+            c, ql = divmod(q, nql)
+            base = h[c * chunk:(c + 1) * chunk]
+            g_ids = base[:arr].view(np.int64).reshape(nql, stride)[ql]
+            g_sc = base[arr:2 * arr].view(np.int64).reshape(nql, stride)[ql]
+            g_cnt = base[2 * arr:2 * arr + 4 * nql].view(np.int32)[ql]
+            g_msz = base[2 * arr + 4 * nql:2 * arr + 8 * nql].view(np.int32)[ql]
+            assert g_cnt == cnt[q] and g_msz == msz[q]
+            assert np.array_equal(g_ids[:g_cnt], ids[q, :g_cnt]) and np.array_equal(g_sc[:g_cnt], sc[q, :g_cnt].view(np.int64))
+        for c in range(n_chunks):
+            assert (h[c * chunk + 2 * arr + 8 * nql:(c + 1) * chunk] == 0xAB).all()
+    qb.bind_outputs(0, 0, 0, 0)  # unbind: the batch's own buffers again
+    qb.run(); qb.finish()
+    again = qb.results()
+    assert np.array_equal(again[0], ids) and np.array_equal(again[2], cnt)
+    qb.close(); index.close()
 
 
 def test_device_fp64_division_sqrt_log_are_bit_exact(pkg, oracle):

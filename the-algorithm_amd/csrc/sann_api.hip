@@ -72,6 +72,8 @@ struct sann_batch {
   DevBuf out_ids, out_scores, out_counts, out_map_sizes, prof;
   // caller-bound output buffers (NULL = the batch's own)
   void *bound_ids = nullptr, *bound_scores = nullptr, *bound_counts = nullptr, *bound_map_sizes = nullptr;
+  int32_t bound_chunk_q = 0;  // 0 = outputs are one chunk
+  int64_t bound_chunk_pitch = 0;
   // general path: workspace and candidate lists for the units it (re)runs, grown on demand
   std::vector<uint32_t> unit_bound;  // upper bound on the postings a unit can scan
   int cap2 = 1;
@@ -126,6 +128,8 @@ struct sann_batch {
     b.out_counts = bound_counts ? (int32_t *)bound_counts : out_counts.as<int32_t>();
     b.out_map_sizes = bound_map_sizes ? (int32_t *)bound_map_sizes : out_map_sizes.as<int32_t>();
     b.stride = stride;
+    b.out_chunk_q = bound_chunk_q > 0 ? bound_chunk_q : (nq > 0 ? nq : 1);
+    b.out_chunk_pitch = bound_chunk_q > 0 ? bound_chunk_pitch : 0;
     b.prof = prof.as<unsigned long long>();
     return b;
   }
@@ -678,6 +682,7 @@ int sann_batch_results(sann_batch_t *b, int64_t *out_ids, double *out_scores, in
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
   if (b->nq == 0) return SANN_OK;
   if (out_stride < b->stride) return fail(SANN_EINVAL, "out_stride smaller than the batch's max k");
+  if (b->bound_chunk_q > 0) return fail(SANN_EINVAL, "outputs are bound to caller-owned chunked buffers");
   HIP_TRY(hipSetDevice(b->ix->device));
   BatchView bv = b->view();
   if (out_ids)
@@ -694,6 +699,7 @@ int sann_batch_results(sann_batch_t *b, int64_t *out_ids, double *out_scores, in
 int sann_batch_device_results(sann_batch_t *b, void **d_ids, void **d_scores, void **d_counts, void **d_map_sizes,
                               int32_t *stride) {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  if (b->bound_chunk_q > 0) return fail(SANN_EINVAL, "outputs are bound to caller-owned chunked buffers");
   BatchView bv = b->view();
   if (d_ids) *d_ids = bv.out_ids;
   if (d_scores) *d_scores = bv.out_scores;
@@ -711,6 +717,23 @@ int sann_batch_bind_outputs(sann_batch_t *b, void *d_ids, void *d_scores, void *
   b->bound_scores = d_scores;
   b->bound_counts = d_counts;
   b->bound_map_sizes = d_map_sizes;
+  b->bound_chunk_q = 0;
+  b->bound_chunk_pitch = 0;
+  return SANN_OK;
+}
+
+int sann_batch_bind_outputs_chunked(sann_batch_t *b, void *d_ids, void *d_scores, void *d_counts, void *d_map_sizes,
+                                    int32_t queries_per_chunk, int64_t chunk_pitch_bytes) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  if (!d_ids || !d_scores || !d_counts || !d_map_sizes) return fail(SANN_EINVAL, "NULL output buffer");
+  if (queries_per_chunk < 1 || chunk_pitch_bytes < 0 || (chunk_pitch_bytes & 7))
+    return fail(SANN_EINVAL, "queries_per_chunk >= 1 and a chunk pitch that is a multiple of 8 bytes");
+  b->bound_ids = d_ids;
+  b->bound_scores = d_scores;
+  b->bound_counts = d_counts;
+  b->bound_map_sizes = d_map_sizes;
+  b->bound_chunk_q = queries_per_chunk;
+  b->bound_chunk_pitch = chunk_pitch_bytes;
   return SANN_OK;
 }
 
@@ -868,18 +891,19 @@ int sann_merge_shards(int32_t device, void *hip_stream, int32_t n_shards, int32_
 }
 
 int sann_merge_shards_cut(int32_t device, void *hip_stream, int32_t n_shards, int32_t nq, int32_t shard_stride,
-                          int32_t shard_k, int32_t k, int32_t out_stride, const void *d_ids, const void *d_scores,
+                          int64_t shard_pitch_bytes, int32_t shard_k, int32_t k, int32_t out_stride, const void *d_ids, const void *d_scores,
                           const void *d_counts, const void *d_map_sizes, void *d_out_ids, void *d_out_scores,
                           void *d_out_counts, void *d_out_map_sizes, void *d_inexact_count) {
   if (n_shards < 1 || nq < 0 || shard_stride < 1 || shard_stride > 1024 || out_stride < 1 || out_stride > 1024)
     return fail(SANN_EINVAL, "bad merge sizes");
   if (shard_k < 1 || shard_k > shard_stride || k < 0) return fail(SANN_EINVAL, "bad shard_k / k");
+  if (shard_pitch_bytes < 0 || (shard_pitch_bytes & 7)) return fail(SANN_EINVAL, "bad shard pitch");
   if (nq == 0) return SANN_OK;
   if (!d_ids || !d_scores || !d_counts || !d_map_sizes || !d_out_ids || !d_out_scores || !d_out_counts || !d_out_map_sizes ||
       !d_inexact_count)
     return fail(SANN_EINVAL, "NULL device pointer");
   HIP_TRY(hipSetDevice(device));
-  HIP_TRY(launch_merge_shards(n_shards, nq, shard_stride, 0, (const int64_t *)d_ids, (const double *)d_scores,
+  HIP_TRY(launch_merge_shards(n_shards, nq, shard_stride, shard_pitch_bytes, (const int64_t *)d_ids, (const double *)d_scores,
                               (const int32_t *)d_counts, (const int32_t *)d_map_sizes, nullptr, k, shard_k, out_stride,
                               (int64_t *)d_out_ids, (double *)d_out_scores, (int32_t *)d_out_counts,
                               (int32_t *)d_out_map_sizes, (int32_t *)d_inexact_count, (hipStream_t)hip_stream));

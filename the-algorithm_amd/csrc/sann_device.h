@@ -87,6 +87,10 @@ struct BatchView {
   int32_t *out_counts;      // [nq]
   int32_t *out_map_sizes;   // [nq]
   int32_t stride;
+  // query q's outputs live in chunk q / out_chunk_q, out_chunk_pitch bytes after the previous chunk's, at
+  // position q % out_chunk_q within it (all four arrays; default: one chunk)
+  int32_t out_chunk_q;
+  int64_t out_chunk_pitch;
   // debug only: per-unit s_memtime stamps at phase boundaries ([n_units*16]); NULL in normal runs
   unsigned long long *prof;
 };

@@ -482,8 +482,10 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
     if (tid == WG - 1) s_off[WG] = wbase + incl;
     __syncthreads();
   }
-  int64_t *out_ids = b.out_ids + (int64_t)q * b.stride;
-  double *out_scores = b.out_scores + (int64_t)q * b.stride;
+  const int out_chunk = q / b.out_chunk_q, ql = q - out_chunk * b.out_chunk_q;
+  const int64_t out_shift = out_chunk * b.out_chunk_pitch;  // bytes
+  int64_t *out_ids = (int64_t *)((char *)b.out_ids + out_shift) + (int64_t)ql * b.stride;
+  double *out_scores = (double *)((char *)b.out_scores + out_shift) + (int64_t)ql * b.stride;
 
   MSTAMP(1);  // offsets
   int best_n = 0;  // entries currently in s_e2
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
       out_scores[i] = key_score(v.x);
     }
     if (cnt == k && cnt > 0) { xk_hi = s_e2[cnt - 1].x; xk_lo = s_e2[cnt - 1].y; }
-    if (tid == 0) b.out_counts[q] = cnt;
+    if (tid == 0) ((int32_t *)((char *)b.out_counts + out_shift))[ql] = cnt;
   }
   __syncthreads();
   // candidateScoresMap.size (:102) and the exactness proof: every candidate a unit withheld has
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   if (inexact) atomicOr(&s_ctl[1], 1);
   __syncthreads();
   if (tid == 0) {
-    b.out_map_sizes[q] = s_ctl[0];
+    ((int32_t *)((char *)b.out_map_sizes + out_shift))[ql] = s_ctl[0];
     if (s_ctl[1]) {
       int o = atomicAdd(&b.status[1], 1);
       b.status[2 + o] = q;  // status[2..] = list of inexact queries

@@ -166,7 +166,8 @@ _PROTOS = {
     "sann_debug_normalise": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
     "sann_batch_bind_outputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sann_merge_shards": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "sann_merge_shards_cut": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 9),
+    "sann_merge_shards_cut": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 9),
+    "sann_batch_bind_outputs_chunked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64]),
 }
 
 
@@ -400,6 +401,13 @@ class QueryBatch:
     def bind_outputs(self, d_ids: int, d_scores: int, d_counts: int, d_map_sizes: int):
         _check(load_library().sann_batch_bind_outputs(self._h, C.c_void_p(d_ids), C.c_void_p(d_scores),
                                                       C.c_void_p(d_counts), C.c_void_p(d_map_sizes)))
+
+    def bind_outputs_chunked(self, d_ids: int, d_scores: int, d_counts: int, d_map_sizes: int, queries_per_chunk: int,
+                             chunk_pitch_bytes: int):
+        """Outputs grouped by owner: query q goes to chunk q // queries_per_chunk (sann_batch_bind_outputs_chunked)."""
+        _check(load_library().sann_batch_bind_outputs_chunked(self._h, C.c_void_p(d_ids), C.c_void_p(d_scores),
+                                                              C.c_void_p(d_counts), C.c_void_p(d_map_sizes),
+                                                              queries_per_chunk, chunk_pitch_bytes))
 
     def device_k(self) -> int:
         p = C.c_void_p()

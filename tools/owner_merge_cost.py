@@ -55,7 +55,7 @@ def full():
 
 
 def cut():
-    assert lib.sann_merge_shards_cut(0, stream, N, nq, shard_k, shard_k, K, K, c_ids.data_ptr(), c_sc.data_ptr(),
+    assert lib.sann_merge_shards_cut(0, stream, N, nq, shard_k, 0, shard_k, K, K, c_ids.data_ptr(), c_sc.data_ptr(),
                                      c_cnt.data_ptr(), c_msz.data_ptr(), o_ids.data_ptr(), o_sc.data_ptr(), o_cnt.data_ptr(),
                                      o_msz.data_ptr(), bad.data_ptr()) == 0
 
