@@ -341,7 +341,7 @@ def test_outputs_bound_in_owner_chunks(pkg, small):
         p = buf.data_ptr()
         qb.bind_outputs_chunked(p, p + arr, p + 2 * arr, p + 2 * arr + 4 * nql, nql, chunk)
         qb.run(); qb.finish()
-        with pytest.raises(pkg.SannError):
+        with pytest.raises(pkg.simclusters_ann.SannError):
             qb.results()
         h = buf.cpu().numpy()
         for q in range(nq):
