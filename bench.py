@@ -70,6 +70,7 @@ def main():
                          "rehearse the N > 1 code path with several ranks sharing one GPU")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="N = 1 only: run the sharded path (process group, all-to-all, owner merge) with one shard")
+    ap.add_argument("--no-overlap", action="store_true", help="sharded runs: exchange and owner merge on the main stream, batch after batch")
     ap.add_argument("--shard-k", type=int, default=0, help="override the per-shard list length of sharded runs (0 = k/N + 6 sigma + 8)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cpu_count, 16))")
     args = ap.parse_args()
@@ -178,10 +179,17 @@ def main():
             # one packed message per owner: [ids nql*stride | score bits nql*stride | counts nql | map sizes nql]
             arr = nql * stride * 8
             chunk = 2 * arr + 8 * nql  # bytes, a multiple of 8
-            send = torch.zeros(world * chunk, dtype=torch.uint8, device="cuda")
-            recv = torch.zeros_like(send)  # [world shards][chunk]: this rank's queries, one chunk per shard
-            sp, rp = send.data_ptr(), recv.data_ptr()
-            qb.bind_outputs_chunked(sp, sp + arr, sp + 2 * arr, sp + 2 * arr + 4 * nql, nql, chunk)
+            # two message buffers: batch i+1 is answered on the main stream while batch i's message travels and is
+            # merged on a side stream (independent batches; every one of them completes inside the timed region)
+            sends = [torch.zeros(world * chunk, dtype=torch.uint8, device="cuda") for _ in range(1 if args.no_overlap else 2)]
+            recv = torch.zeros_like(sends[0])  # [world shards][chunk]: this rank's queries, one chunk per shard
+            rp = recv.data_ptr()
+            main_stream = torch.cuda.current_stream()
+            side_stream = main_stream if args.no_overlap else torch.cuda.Stream()
+            sent = [None] * len(sends)  # event: the exchange that read sends[slot] has finished
+            ready = [torch.cuda.Event() for _ in sends]  # event: the batch in sends[slot] is final
+            pending = [None]  # slot of the finished batch whose message has not been sent yet
+            n_steps_done = [0]
             out_ids = torch.zeros((nql, K), dtype=torch.int64, device="cuda")
             out_sc = torch.zeros((nql, K), dtype=torch.float64, device="cuda")
             out_cnt = torch.zeros(nql, dtype=torch.int32, device="cuda")
@@ -199,24 +207,52 @@ def main():
             else:
                 dist.all_to_all_single(recv, send)
 
-        def step():
-            qb.run(stream)
-            qb.finish(stream)  # waits for the stream; re-runs whatever the fast path flagged, before anything is sent
-            if sharded:
-                exchange(send, recv)
+        def post(slot):
+            """Exchange + owner merge of a finished batch, on the side stream."""
+            with torch.cuda.stream(side_stream):
+                if not args.no_overlap:
+                    side_stream.wait_event(ready[slot])
+                exchange(sends[slot], recv)
+                if not args.no_overlap:
+                    sent[slot] = torch.cuda.Event()
+                    sent[slot].record(side_stream)
+                side = ctypes.c_void_p(side_stream.cuda_stream)
                 if shard_k < K:
-                    rc = lib.sann_merge_shards_cut(local_rank, ctypes.c_void_p(stream), world, nql, stride, chunk, shard_k, K, K,
+                    rc = lib.sann_merge_shards_cut(local_rank, side, world, nql, stride, chunk, shard_k, K, K,
                                                    rp, rp + arr, rp + 2 * arr, rp + 2 * arr + 4 * nql,
                                                    out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr(),
                                                    d_bad.data_ptr())
                 else:
-                    rc = lib.sann_merge_shards(local_rank, ctypes.c_void_p(stream), world, nql, stride, chunk, rp, rp + arr,
+                    rc = lib.sann_merge_shards(local_rank, side, world, nql, stride, chunk, rp, rp + arr,
                                                rp + 2 * arr, rp + 2 * arr + 4 * nql,
                                                d_k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr())
                 assert rc == 0, lib.sann_last_error()
 
+        def step():
+            if sharded:
+                slot = n_steps_done[0] % len(sends)
+                n_steps_done[0] += 1
+                if sent[slot] is not None:
+                    main_stream.wait_event(sent[slot])  # the message buffer is free again
+                sp = sends[slot].data_ptr()
+                qb.bind_outputs_chunked(sp, sp + arr, sp + 2 * arr, sp + 2 * arr + 4 * nql, nql, chunk)
+            qb.run(stream)  # asynchronous: descriptor, unit and merge kernels of this batch
+            if sharded and pending[0] is not None:
+                post(pending[0])  # the previous batch's message leaves while this batch is being answered
+                pending[0] = None
+            qb.finish(stream)  # waits for the stream; re-runs whatever the fast path flagged, before anything is sent
+            if sharded:
+                if args.no_overlap:
+                    post(slot)
+                else:
+                    ready[slot].record(main_stream)
+                    pending[0] = slot
+
         def sync():
             if sharded:
+                if pending[0] is not None:
+                    post(pending[0])
+                    pending[0] = None
                 torch.cuda.synchronize()
                 dist.barrier()
                 torch.cuda.synchronize()
