@@ -70,7 +70,10 @@ def main():
                          "rehearse the N > 1 code path with several ranks sharing one GPU")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="N = 1 only: run the sharded path (process group, all-to-all, owner merge) with one shard")
-    ap.add_argument("--no-overlap", action="store_true", help="sharded runs: exchange and owner merge on the main stream, batch after batch")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight: consecutive steps alternate between this many batch objects / HIP streams")
+    ap.add_argument("--serial-kernels", action="store_true",
+                    help="batches in flight, but a batch's unit kernel waits for the previous batch's merge kernel (only the descriptor kernel and the host overlap)")
+    ap.add_argument("--no-overlap", action="store_true", help="one batch at a time on one stream (and, sharded, exchange and owner merge on that stream too)")
     ap.add_argument("--shard-k", type=int, default=0, help="override the per-shard list length of sharded runs (0 = k/N + 6 sigma + 8)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cpu_count, 16))")
     args = ap.parse_args()
@@ -79,6 +82,9 @@ def main():
         tool = os.path.join(ROOT, "tools", "dense_bench.py" if args.workload == "dense" else "hnsw_bench.py")
         sys.exit(subprocess.run([sys.executable, tool, "--steps", str(max(1, min(args.steps, 5)))]).returncode)
 
+    # batches in flight use a few HIP streams (two batch streams, the exchange stream, RCCL's own); the runtime
+    # multiplexes streams onto 4 hardware queues by default, and two streams on one queue run in order
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,37 +171,55 @@ def main():
     inexact_seen = 0
     while True:
         cfg_run = cfg if shard_k == K else dataclasses.replace(cfg, maxNumResults=shard_k)
-        qb = pkg.QueryBatch(index, offs, cids, scs, cfg_run, now_ms=now_ms)
-        stride = qb.stride
-        stream = 0
+        # Batches in flight: consecutive steps alternate between `depth` QueryBatch objects (own workspaces and
+        # outputs, same queries) on their own HIP streams, so the GPU always has the next batch queued: batch i+1's
+        # descriptor / unit kernels run beside batch i's merge kernel (LDS-bound, one round of workgroups), and the
+        # host's per-batch stream wait + status check (sann_batch_finish) is off the GPU's critical path.  Every batch
+        # is complete (finished, checked, and when sharded exchanged and merged) before the timed region ends.
+        depth = 1 if args.no_overlap else max(1, args.inflight)
+        qbs = [pkg.QueryBatch(index, offs, cids, scs, cfg_run, now_ms=now_ms) for _ in range(depth)]
+        stride = qbs[0].stride
+        if sharded:
+            t_streams = [torch.cuda.current_stream()] if depth == 1 else [torch.cuda.Stream() for _ in range(depth)]
+            streams = [t.cuda_stream for t in t_streams]
+        elif depth == 1:
+            streams = [0]
+        else:
+            hip = ctypes.CDLL("libamdhip64.so")
+            streams = []
+            for _ in range(depth):
+                h_stream = ctypes.c_void_p()
+                assert hip.hipStreamCreateWithFlags(ctypes.byref(h_stream), 1) == 0  # hipStreamNonBlocking
+                streams.append(h_stream.value)
+        launched = []  # slots whose batch is enqueued but not yet finished, oldest first
+        n_steps_done = [0]
+        alone = [False]  # True: one batch at a time, nothing overlapped (the per-kernel timings after the timed region)
 
         # ---- multi-GPU plumbing: per-shard answers -> all-to-all by query owner -> exact merge ----------
         # Rank r owns queries [r*nql, (r+1)*nql).  Every rank answers all nq queries on its tweet-hash shard;
         # the merge kernel writes query q's results straight into the message of its owner, and ONE all-to-all
         # (RCCL over xGMI: (world-1)/world of nq*shard_k*16 B leaves each GPU, the same amount arrives) delivers
-        # them; the owner merges world per-shard lists.
+        # them; the owner merges world per-shard lists.  Exchange and owner merge run on a side stream.
         if sharded:
-            stream = torch.cuda.current_stream().cuda_stream
             # one packed message per owner: [ids nql*stride | score bits nql*stride | counts nql | map sizes nql]
             arr = nql * stride * 8
             chunk = 2 * arr + 8 * nql  # bytes, a multiple of 8
-            # two message buffers: batch i+1 is answered on the main stream while batch i's message travels and is
-            # merged on a side stream (independent batches; every one of them completes inside the timed region)
-            sends = [torch.zeros(world * chunk, dtype=torch.uint8, device="cuda") for _ in range(1 if args.no_overlap else 2)]
+            sends = [torch.zeros(world * chunk, dtype=torch.uint8, device="cuda") for _ in range(depth)]
             recv = torch.zeros_like(sends[0])  # [world shards][chunk]: this rank's queries, one chunk per shard
             rp = recv.data_ptr()
-            main_stream = torch.cuda.current_stream()
-            side_stream = main_stream if args.no_overlap else torch.cuda.Stream()
-            sent = [None] * len(sends)  # event: the exchange that read sends[slot] has finished
+            side_stream = t_streams[0] if args.no_overlap else torch.cuda.Stream()
+            sent = [None] * depth  # event: the exchange that read sends[slot] has finished
             ready = [torch.cuda.Event() for _ in sends]  # event: the batch in sends[slot] is final
-            pending = [None]  # slot of the finished batch whose message has not been sent yet
-            n_steps_done = [0]
+            for j, qb in enumerate(qbs):
+                sp = sends[j].data_ptr()
+                qb.bind_outputs_chunked(sp, sp + arr, sp + 2 * arr, sp + 2 * arr + 4 * nql, nql, chunk)
             out_ids = torch.zeros((nql, K), dtype=torch.int64, device="cuda")
             out_sc = torch.zeros((nql, K), dtype=torch.float64, device="cuda")
             out_cnt = torch.zeros(nql, dtype=torch.int32, device="cuda")
             out_msz = torch.zeros(nql, dtype=torch.int32, device="cuda")
-            d_k = qb.device_k() + rank * nql * 4
+            d_k = qbs[0].device_k() + rank * nql * 4
             d_bad = torch.zeros(1, dtype=torch.int32, device="cuda")  # queries whose cut per-shard lists could not prove the merge exact
+            torch.cuda.synchronize()  # the buffers were zero-filled on the default stream; they are used on others
 
         def exchange(send, recv):
             if args.backend == "gloo":  # rehearsal: gloo has no all-to-all; gather on the host and slice
@@ -209,13 +233,12 @@ def main():
 
         def post(slot):
             """Exchange + owner merge of a finished batch, on the side stream."""
+            ready[slot].record(t_streams[slot])
             with torch.cuda.stream(side_stream):
-                if not args.no_overlap:
-                    side_stream.wait_event(ready[slot])
+                side_stream.wait_event(ready[slot])
                 exchange(sends[slot], recv)
-                if not args.no_overlap:
-                    sent[slot] = torch.cuda.Event()
-                    sent[slot].record(side_stream)
+                sent[slot] = torch.cuda.Event()
+                sent[slot].record(side_stream)
                 side = ctypes.c_void_p(side_stream.cuda_stream)
                 if shard_k < K:
                     rc = lib.sann_merge_shards_cut(local_rank, side, world, nql, stride, chunk, shard_k, K, K,
@@ -228,31 +251,32 @@ def main():
                                                d_k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr())
                 assert rc == 0, lib.sann_last_error()
 
+        def retire(slot):
+            # waits for the batch's stream and re-runs whatever the fast path flagged, before anything is sent
+            qbs[slot].finish(streams[slot])
+            if sharded:
+                post(slot)
+
         def step():
-            if sharded:
-                slot = n_steps_done[0] % len(sends)
-                n_steps_done[0] += 1
-                if sent[slot] is not None:
-                    main_stream.wait_event(sent[slot])  # the message buffer is free again
-                sp = sends[slot].data_ptr()
-                qb.bind_outputs_chunked(sp, sp + arr, sp + 2 * arr, sp + 2 * arr + 4 * nql, nql, chunk)
-            qb.run(stream)  # asynchronous: descriptor, unit and merge kernels of this batch
-            if sharded and pending[0] is not None:
-                post(pending[0])  # the previous batch's message leaves while this batch is being answered
-                pending[0] = None
-            qb.finish(stream)  # waits for the stream; re-runs whatever the fast path flagged, before anything is sent
-            if sharded:
-                if args.no_overlap:
-                    post(slot)
-                else:
-                    ready[slot].record(main_stream)
-                    pending[0] = slot
+            slot = n_steps_done[0] % depth
+            n_steps_done[0] += 1
+            if sharded and sent[slot] is not None:
+                t_streams[slot].wait_event(sent[slot])  # the message buffer is free again
+            # asynchronous: descriptor, unit and merge kernels of this batch; the unit kernel waits on the GPU for the
+            # previous batch's unit kernel (the dominant kernels run one at a time, everything else overlaps)
+            if depth > 1 and not alone[0]:
+                qbs[slot].run_after(streams[slot], qbs[(slot - 1) % depth], after_merge=args.serial_kernels)
+            else:
+                qbs[slot].run(streams[slot])
+            launched.append(slot)
+            # keep depth-1 batches queued behind the one the host now waits for (none when timing kernels alone)
+            while len(launched) > (0 if alone[0] else depth - 1):
+                retire(launched.pop(0))
 
         def sync():
+            while launched:
+                retire(launched.pop(0))
             if sharded:
-                if pending[0] is not None:
-                    post(pending[0])
-                    pending[0] = None
                 torch.cuda.synchronize()
                 dist.barrier()
                 torch.cuda.synchronize()
@@ -274,30 +298,39 @@ def main():
             step()
         # the timed region carries HIP events around the dominant kernel only (two per step; each event costs the
         # stream ~5 us); the descriptor and merge kernels are timed over a few extra steps afterwards
-        qb.set_profiling(1)
         sync()
+        for qb in qbs:
+            qb.set_profiling(1)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         sync()
         elapsed = time.perf_counter() - t0
-        unit_ms, _m, n_timed = qb.kernel_times()
-        qb.set_profiling(2)
+        unit_ms = sum(qb.kernel_times()[0] for qb in qbs)
+        n_timed = sum(qb.kernel_times()[2] for qb in qbs)
+        for qb in qbs:
+            qb.set_profiling(2)
+        alone[0] = True  # a few more steps, one batch at a time: each kernel's duration with the GPU to itself
         n_aux = max(3, min(10, args.steps))
         for _ in range(n_aux):
             step()
         sync()
-        _u, merge_ms, _n = qb.kernel_times()
-        desc_ms = qb.desc_time()
+        alone[0] = False
+        unit_alone_ms = sum(qb.kernel_times()[0] for qb in qbs) / n_aux
+        merge_ms = sum(qb.kernel_times()[1] for qb in qbs)
+        desc_ms = sum(qb.desc_time() for qb in qbs)
         merge_ms, desc_ms = merge_ms * n_timed / n_aux, desc_ms * n_timed / n_aux  # reported as per-launch averages below
-        qb.set_profiling(False)
+        for qb in qbs:
+            qb.set_profiling(False)
+        last = qbs[(n_steps_done[0] - 1) % depth]  # the batch of the last step
         # ---- results of the last step (this rank's own queries when sharded) -----------------------
         if sharded:
             torch.cuda.synchronize()
             ids, scores, counts, msz = out_ids.cpu().numpy(), out_sc.cpu().numpy(), out_cnt.cpu().numpy(), out_msz.cpu().numpy()
         else:
-            ids, scores, counts, msz = qb.results()
-        st = qb.stats()
+            ids, scores, counts, msz = last.results()
+        st = last.stats()
+        n_fallback_units = sum(int(qb.stats().n_fallback_units) for qb in qbs)
         candidates_per_step = int(counts.sum())
         if sharded:
             dev = "cpu" if args.backend == "gloo" else "cuda"
@@ -312,7 +345,8 @@ def main():
                 # is repeated with full-length per-shard lists (expected never; the proof is checked every batch)
                 inexact_seen += int(tc[1].item())
                 shard_k = K
-                qb.close()
+                for qb in qbs:
+                    qb.close()
                 continue
         break
     value = candidates_per_step * args.steps / elapsed
@@ -377,7 +411,12 @@ def main():
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic_bytes(args, nq, world), "kernel": "sann::unit_fast_kernel (gather+accumulate+select)",
             "kernel_avg_ms": unit_avg_ms, "desc_kernel_avg_ms": desc_ms / max(n_timed, 1),
-            "merge_kernel_avg_ms": merge_ms / max(n_timed, 1), "algorithmic_bytes_per_launch": alg_bytes}
+            "merge_kernel_avg_ms": merge_ms / max(n_timed, 1), "algorithmic_bytes_per_launch": alg_bytes,
+            # the timed region keeps batches in flight, so its unit kernel shares the GPU with the previous batch's
+            # merge kernel and the next batch's descriptor kernel; *_alone = the same launch with the GPU to itself
+            # (steps after the timed region, one batch at a time), as are the desc / merge figures above
+            "kernel_avg_ms_alone": unit_alone_ms,
+            "frac_alone": (alg_bytes / (unit_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if unit_alone_ms > 0 else 0.0}
 
     line = {
         "metric": "candidates/sec + recall@400, 100M-tweet SimClusters-ANN @1/2/4/8 GPU",
@@ -398,6 +437,7 @@ def main():
                    "max_top_tweets_per_cluster": 800, "algorithm": args.alg, "index_cap": 2000,
                    "partitions": index.info().n_partitions, "sharding": "none" if world == 1 else "tweet-hash",
                    "shard_list_length": shard_k, "queries_not_proven_by_cut_lists": inexact_seen,
+                   "batches_in_flight": depth,
                    "corpus": args.corpus, "index_postings": int(index.info().n_postings_total)},
         "queries_per_sec": nq * args.steps / elapsed,
         "postings_per_sec": int(st.postings_scanned) * args.steps / elapsed,
@@ -405,7 +445,7 @@ def main():
         "recall_at_400_quality": recall_quality,
         "quality_checked_queries": (min(args.quality_queries, nq) if recall_quality is not None else 0),
         "parity_checked_queries": n_check,
-        "fallback_units": int(st.n_fallback_units),
+        "fallback_units": n_fallback_units,
         "sharded_equals_unsharded": check_sharded_against_unsharded() if (world > 1 and args.backend == "gloo") else None,
         "roofline": roof,
         "cpu_baseline": cpu,

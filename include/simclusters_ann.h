@@ -190,6 +190,13 @@ int sann_batch_create(sann_index_t *index, int32_t variant, int64_t now_ms, int3
 /* Enqueue the batch on `hip_stream` (a hipStream_t, NULL = the null stream). Asynchronous;
  * may be called repeatedly (results are overwritten). */
 int sann_batch_run(sann_batch_t *batch, void *hip_stream);
+
+/* The same for batches kept in flight on different streams: the dominant (unit) kernel of `batch` does not start
+ * before that of `after` (a batch enqueued earlier with this function on another stream; NULL = no predecessor)
+ * has finished -- a cross-stream event, no host wait.  Everything else overlaps: this batch's descriptor kernel
+ * and its unit kernel run beside `after`'s merge kernel, and the host's wait in sann_batch_finish is off the
+ * GPU's critical path.  Per-launch kernel durations stay meaningful because unit kernels never run side by side. */
+int sann_batch_run_after(sann_batch_t *batch, void *hip_stream, sann_batch_t *after, int32_t after_merge);
 /* Wait for the batch, re-running on the general path whatever the fast path flagged. After
  * this returns SANN_OK the device results are final and exact. */
 int sann_batch_finish(sann_batch_t *batch, void *hip_stream);

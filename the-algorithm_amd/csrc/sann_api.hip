@@ -73,6 +73,10 @@ struct sann_batch {
   // caller-bound output buffers (NULL = the batch's own)
   void *bound_ids = nullptr, *bound_scores = nullptr, *bound_counts = nullptr, *bound_map_sizes = nullptr;
   int32_t bound_chunk_q = 0;  // 0 = outputs are one chunk
+  hipEvent_t ev_unit_done = nullptr;  // sann_batch_run_after: recorded behind the unit kernel(s)
+  hipEvent_t last_unit_done = nullptr;
+  hipEvent_t ev_all_done = nullptr;  // sann_batch_run_after: recorded behind the merge kernel
+  bool unit_done_recorded = false;
   int64_t bound_chunk_pitch = 0;
   // general path: workspace and candidate lists for the units it (re)runs, grown on demand
   std::vector<uint32_t> unit_bound;  // upper bound on the postings a unit can scan
@@ -98,6 +102,8 @@ struct sann_batch {
   ~sann_batch() {
     if (h_status) (void)hipHostFree(h_status);
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    if (ev_unit_done) (void)hipEventDestroy(ev_unit_done);
+    if (ev_all_done) (void)hipEventDestroy(ev_all_done);
   }
 
   BatchView view() const {
@@ -572,10 +578,13 @@ int run_general(sann_batch *b, const std::vector<int32_t> &units, hipStream_t st
 
 extern "C" {
 
-int sann_batch_run(sann_batch_t *b, void *hip_stream) {
+static int batch_run(sann_batch_t *b, void *hip_stream, bool chained, sann_batch_t *after, bool whole) {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  if (after && after->ix->device != b->ix->device) return fail(SANN_EINVAL, "batches on different devices");
   hipStream_t st = (hipStream_t)hip_stream;
   HIP_TRY(hipSetDevice(b->ix->device));
+  if (chained && !b->ev_unit_done) HIP_TRY(hipEventCreateWithFlags(&b->ev_unit_done, hipEventDisableTiming));
+  if (chained && !b->ev_all_done) HIP_TRY(hipEventCreateWithFlags(&b->ev_all_done, hipEventDisableTiming));
   if (b->nq == 0) { b->ran = true; return SANN_OK; }
   if (!b->use_fast) {  // the fast path's descriptor kernel clears these itself
     HIP_TRY(hipMemsetAsync(b->status.p, 0, ((size_t)b->nq + 2) * 4, st));
@@ -592,6 +601,9 @@ int sann_batch_run(sann_batch_t *b, void *hip_stream) {
     if (b->use_fast) {
       hipError_t e = launch_desc(b->ix->view(), b->view(), b->n_units, st);
       if (e != hipSuccess) return fail(SANN_EDEVICE, std::string("launch_desc: ") + hipGetErrorString(e));
+      // the descriptor kernel may run beside anything; the dominant kernel waits for its predecessor's
+      if (after && after != b && after->unit_done_recorded)
+        HIP_TRY(hipStreamWaitEvent(st, whole ? after->ev_all_done : after->last_unit_done, 0));
       if (b->profiling) HIP_TRY(hipEventRecord(b->ev[3], st));
       e = launch_unit_fast(b->ix->view(), b->view(), b->fast, b->n_units, st);
       if (e != hipSuccess) return fail(SANN_EDEVICE, std::string("launch_unit_fast: ") + hipGetErrorString(e));
@@ -602,14 +614,26 @@ int sann_batch_run(sann_batch_t *b, void *hip_stream) {
     }
   }
   if (b->profiling) HIP_TRY(hipEventRecord(b->ev[1], st));
+  if (chained) {  // the profiling bracket's closing event doubles as the marker (an event costs the stream ~5 us)
+    if (!b->profiling) HIP_TRY(hipEventRecord(b->ev_unit_done, st));
+    b->last_unit_done = b->profiling ? b->ev[1] : b->ev_unit_done;
+    b->unit_done_recorded = true;
+  }
   HIP_TRY(launch_merge(b->ix->view(), b->view(), nullptr, b->nq, st));
   if (b->profiling) {
     if (!b->prof_unit_only) HIP_TRY(hipEventRecord(b->ev[2], st));
     b->ev_pending = true;
   }
+  if (chained) HIP_TRY(hipEventRecord(b->ev_all_done, st));
   HIP_TRY(hipMemcpyAsync(b->h_status, b->status.p, 2 * 4, hipMemcpyDeviceToHost, st));
   b->ran = true;
   return SANN_OK;
+}
+
+int sann_batch_run(sann_batch_t *b, void *hip_stream) { return batch_run(b, hip_stream, false, nullptr, false); }
+
+int sann_batch_run_after(sann_batch_t *b, void *hip_stream, sann_batch_t *after, int32_t after_merge) {
+  return batch_run(b, hip_stream, true, after, after_merge != 0);
 }
 
 int sann_batch_finish(sann_batch_t *b, void *hip_stream) {

@@ -148,6 +148,7 @@ _PROTOS = {
     "sann_index_destroy": (C.c_int, [C.c_void_p]),
     "sann_batch_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "sann_batch_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sann_batch_run_after": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "sann_batch_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sann_batch_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "sann_batch_device_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
@@ -380,6 +381,11 @@ class QueryBatch:
 
     def run(self, stream: int = 0):
         _check(load_library().sann_batch_run(self._h, C.c_void_p(stream)))
+
+    def run_after(self, stream: int, after: "Optional[QueryBatch]", after_merge: bool = True):
+        """sann_batch_run_after: this batch's unit kernel waits (on the GPU) for `after`'s merge (or unit) kernel."""
+        _check(load_library().sann_batch_run_after(self._h, C.c_void_p(stream), after._h if after is not None else None,
+                                                   1 if after_merge else 0))
 
     def finish(self, stream: int = 0):
         _check(load_library().sann_batch_finish(self._h, C.c_void_p(stream)))
