@@ -362,6 +362,53 @@ def test_outputs_bound_in_owner_chunks(pkg, small):
     qb.close(); index.close()
 
 
+def same_results(got, want):
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+    for q, n in enumerate(want[2]):
+        assert np.array_equal(got[0][q, :n], want[0][q, :n])
+        assert np.array_equal(got[1][q, :n].view(np.int64), want[1][q, :n].view(np.int64))
+
+
+@pytest.mark.parametrize("after_merge", [False, True])
+def test_batches_in_flight_on_two_streams(pkg, small, after_merge):
+    """sann_batch_run_after: two batches alternate on two non-blocking streams, each unit kernel ordered behind
+    the other batch's by a cross-stream event; every pass gives exactly the results of a plain run."""
+    import ctypes as C
+
+    co, offs, cids, scs = small
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=8)
+    cfgs = [pkg.SimClustersANNConfig(maxNumResults=400, maxTopTweetsPerCluster=300),
+            pkg.SimClustersANNConfig(maxNumResults=37, maxTopTweetsPerCluster=120, annAlgorithm=pkg.ScoringAlgorithm.DotProduct)]
+    want = []
+    for cfg in cfgs:
+        out, _ = run_batch(pkg, index, co, offs, cids, scs, cfg)
+        want.append(out)
+    hip = C.CDLL("libamdhip64.so")
+    streams = []
+    for _ in range(2):
+        h = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(h), 1) == 0
+        streams.append(h.value)
+    qbs = [pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=co.now_ms) for cfg in cfgs]
+    launched = []
+    for i in range(9):
+        j = i & 1
+        qbs[j].run_after(streams[j], qbs[1 - j], after_merge=after_merge)
+        launched.append(j)
+        if len(launched) > 1:
+            d = launched.pop(0)
+            qbs[d].finish(streams[d])
+            same_results(qbs[d].results(), want[d])
+    d = launched.pop(0)
+    qbs[d].finish(streams[d])
+    same_results(qbs[d].results(), want[d])
+    for qb in qbs:
+        qb.close()
+    for st in streams:
+        assert hip.hipStreamDestroy(C.c_void_p(st)) == 0
+    index.close()
+
+
 def test_device_fp64_division_sqrt_log_are_bit_exact(pkg, oracle):
     """The normalisation (ApproximateCosineSimilarity.scala:111-119) evaluated on the device equals
     the host's IEEE result bit for bit: correctly rounded / and sqrt, and the fdlibm log."""
