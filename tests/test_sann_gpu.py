@@ -120,6 +120,22 @@ def test_per_query_configs_sources_and_windows(pkg, oracle, small):
     index.close()
 
 
+@pytest.mark.parametrize("P", [2, 8])
+@pytest.mark.parametrize("k", [1, 37, 104, 256, 257])
+def test_few_partitions_small_k_merge(pkg, oracle, small, P, k):
+    """Shape of a sharded run (<= 8 partitions, short result lists): the merge kernel's small-LDS variant
+    (256 survivors, 640 staged entries, several tournament rounds when the units' lists are long) and, at
+    k = 257, the hand-over to the 512-survivor variant."""
+    co, offs, cids, scs = small
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=P)
+    for alg in (1, 3):
+        cfg = pkg.SimClustersANNConfig(maxNumResults=k, maxTopTweetsPerCluster=400, annAlgorithm=pkg.ScoringAlgorithm(alg),
+                                       maxTweetCandidateAgeHours=175200)
+        out, st = run_batch(pkg, index, co, offs, cids, scs, cfg)
+        check_against_oracle(pkg, oracle, co, offs, cids, scs, cfg, out)
+    index.close()
+
+
 def test_heavy_duplication_and_explicit_order(pkg, oracle):
     """Every cluster lists the SAME tweets: each candidate is a 40-term ordered fp64 sum, and the
     explicit key order changes last-ulp results (accumulation order is the caller's)."""

@@ -439,9 +439,11 @@ __device__ void lds_radix_cut(const uint64_t *hi, const uint64_t *lo, int n, int
 // SURV = capacity of the survivor list: 512 when every k of the batch is <= 448, else 1024.  The staging
 // area holds 1728 entries for SURV = 512: 39.8 KB of LDS in all, FOUR workgroups per CU, so a 1024-query batch
 // merges in one round of workgroups (at 2048 entries it was 44 KB, three per CU, two rounds: twice the time).
-template <int SURV>
+// MERGE_LDS = entries staged per tournament round (>= SURV + any per-unit capacity): 1728 for the 32-partition
+// benchmark shape; 768 when the index has <= 8 partitions per cluster and k <= 256 (sharded runs: ~500 candidates
+// per query in all) -- 24 KB of LDS instead of 40, six workgroups per CU instead of four.
+template <int SURV, int MERGE_LDS>
 __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, const int32_t *query_list) {
-  constexpr int MERGE_LDS = SURV == 512 ? 1728 : 2048;  // entries staged per tournament round; >= SURV + any per-unit capacity
   __shared__ uint64_t s_hi[MERGE_LDS], s_lo[MERGE_LDS];
   __shared__ uint8_t s_umap[MERGE_LDS];  // new entry -> unit (relative to the round's first unit; P <= 256)
   __shared__ ulonglong2 s_e2[SURV];  // survivors, packed {score key, id key}
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   const int P = ix.P;  // <= 256
   const int64_t unit0 = (int64_t)q * P;
   const int k = h.k;
-  const int budget = (k <= 448 || SURV < KMAX) ? 512 : KMAX;  // survivors kept between chunks / sorted at the end
+  const int budget = SURV < 512 ? SURV : (k <= 448 || SURV < KMAX) ? 512 : KMAX;  // survivors kept between chunks / sorted at the end
   // debug stamps live after the units' region of the prof buffer
 #define MSTAMP(i) do { if (b.prof && tid == 0) b.prof[((int64_t)b.nq * P + q) * 16 + (i)] = (unsigned long long)clock64(); } while (0)
   MSTAMP(0);
@@ -693,8 +695,12 @@ hipError_t launch_merge(const IndexView &ix, const BatchView &b, const int32_t *
                         hipStream_t stream) {
   if (n_queries <= 0) return hipSuccess;
   // the 512-entry survivor list serves k <= 448; cap2 is the batch's largest k
-  if (b.cap2 <= 448) hipLaunchKernelGGL(merge_kernel<512>, dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
-  else hipLaunchKernelGGL(merge_kernel<KMAX>, dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
+  if (ix.P <= 8 && b.cap2 <= 256 && b.cap <= 256)  // a single list (<= 256 entries) fits beside 512 survivors
+    hipLaunchKernelGGL((merge_kernel<256, 640>), dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
+  else if (b.cap2 <= 448)
+    hipLaunchKernelGGL((merge_kernel<512, 1728>), dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
+  else
+    hipLaunchKernelGGL((merge_kernel<KMAX, 2048>), dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
   return hipGetLastError();
 }
 hipError_t launch_merge_shards(int n_shards, int nq, int stride, int64_t pitch, const int64_t *ids, const double *scores,

@@ -32,5 +32,25 @@ for _once in (0,):
     d = qb.desc_time()
     qb.set_profiling(False)
     st = qb.stats()
+    # the same with two batches in flight (bench.py's default): unit kernels chained across two streams
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    streams = []
+    for _ in range(2):
+        h = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(h), 1) == 0
+        streams.append(h.value)
+    qb2 = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=pkg.corpus.NOW_MS)
+    pair = [qb, qb2]
+    for rep in range(2):
+        t0 = time.perf_counter()
+        for i in range(20):
+            j = i & 1
+            pair[j].run_after(streams[j], pair[1 - j], after_merge=False)
+            if i:
+                pair[1 - j].finish(streams[1 - j])
+        pair[1].finish(streams[1])
+        wall2 = (time.perf_counter() - t0) / 20
+    print(f"N={N} P={P} k={K}: two batches in flight: step {wall2 * 1e3:.3f} ms")
     print(f"N={N} P={P} k={K}: step {wall * 1e3:.3f} ms, fallback/step {(st.n_fallback_units - fb0) / 10:.0f}, desc {d / n * 1e3:.0f} us, unit {u / n * 1e3:.0f} us, merge {m / n * 1e3:.0f} us, "
           f"fallback units {st.n_fallback_units}, units {st.n_units}")
