@@ -257,23 +257,32 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 8 ? 5 : 3)) v
     id[u] = 0;
     sc[u] = 0.0;
   }
-  if (!overflow) {
+  {
+    // an overflowed unit gathers nothing: with Tg = 0 every slot below is skipped, and no separate control path
+    // has to be merged with the loaded registers (the merge made hipcc wait for the first slot's load at once)
+    const uint32_t Tg = overflow ? 0u : T;
     Posting pst[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      pst[u].id = 0;
-      pst[u].score = 0.0;
-      if ((uint32_t)(u * WG) < T) {  // uniform: skip register slots the unit does not reach
+    for (int uu = 0; uu < U; uu++) {
+      const int u = U - 1 - uu;  // last slot first (see the note at the second loop)
+      if ((uint32_t)(u * WG) < Tg) {  // uniform: skip register slots the unit does not reach (pst[u] stays unset, unused)
+        // lanes past the end re-read the unit's last posting (dead: seq = -1): an unconditional load keeps the
+        // slots' loads free of per-lane control flow, so all of them are in flight before the first is used
         const uint32_t j = (uint32_t)(u * WG + tid);
-        const int c = (j < T) ? (int)s_map[j] : 0;
-        seq[u] = (j < T) ? c : -1;
-        if (j < T) pst[u] = ix.postings[s_begin[c] + (j - s_pre[c])];
+        const uint32_t jj = j < Tg ? j : Tg - 1;
+        const int c = (int)s_map[jj];
+        seq[u] = (j < Tg) ? c : -1;
+        pst[u] = ix.postings[s_begin[c] + (jj - s_pre[c])];
       }
     }
     STAMP(2);  // posting loads issued
+    // the same bound, made opaque: hipcc otherwise threads each slot's "use" block onto its "issue" block (same
+    // uniform condition) and, for slot 0, waited for that slot's load before the other loads were even issued
+    uint32_t Tu = Tg;
+    asm volatile("" : "+s"(Tu));
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if ((uint32_t)(u * WG) < T) {
+      if ((uint32_t)(u * WG) < Tu) {
         // NB: selects, not `seq[u] = -1; continue;` -- hipcc (ROCm 7.2) mis-structurised that form
         // and dropped the -1 for postings outside the age window.
         const bool have = seq[u] >= 0;
