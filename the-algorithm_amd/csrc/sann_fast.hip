@@ -220,18 +220,20 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 8 ? 5 : 3)) v
   for (int i = tid; i < BLOOM_ALLOC; i += WG) s_bloom[i] = 0ull;
   for (int i = tid; i < FBLOOM_WORDS; i += WG) s_fbloom[i] = 0ull;
 
-  bool overflow = h.n_scan > NSCAN_MAX;  // uniform
-  int why = overflow ? 1 : 0;  // overflow reason (kept in unit_thr[2u+1] for diagnostics)
+  const bool overflow_n = h.n_scan > NSCAN_MAX;  // uniform
   // ---- 1. descriptors ----------------------------------------------------------------------
-  const uint32_t T = overflow ? 0u : (uint32_t)b.unit_T[unit];
-  if (!overflow && T > (uint32_t)(WG * U)) { overflow = true; why = 2; }
-  if (!overflow) {
+  // The unit's posting count T and its descriptor row are loaded together: nothing below branches on T before
+  // the descriptor loads are issued (a branch on T first cost a second, serial trip to memory).
+  // (Tv stays a per-lane register until after the loop: a scalar copy would make hipcc wait for it right here)
+  uint32_t Tv = overflow_n ? 0u : (uint32_t)b.unit_T[unit];
+  if (!overflow_n) {
     const uint32_t *d = b.desc + 2 * ((int64_t)h.scan_begin * ix.P + (int64_t)p * h.n_scan);
     // four lanes per cluster: lane part (0..3) fills a quarter of the cluster's stretch of the map
     for (int t = tid; t < 4 * h.n_scan; t += WG) {
       const int c = t >> 2, part = t & 3;
       const uint2 v = *reinterpret_cast<const uint2 *>(d + 2 * c);
-      const uint32_t next = (c + 1 < h.n_scan) ? d[2 * (c + 1) + 1] : T;
+      const bool last = c + 1 >= h.n_scan;
+      uint32_t nxt = last ? 0u : d[2 * (c + 1) + 1];
       if (part == 0) {
         const double w = b.scan_w[h.scan_begin + c];
         s_begin[c] = v.x;
@@ -239,10 +241,18 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 8 ? 5 : 3)) v
         s_w[c] = w;
         s_w32[c] = (float)w;
       }
-      // every posting of this cluster records its cluster in the flat map
+      // every posting of this cluster records its cluster in the flat map (an oversized unit stops at the map's end)
+      asm volatile("" : "+v"(nxt));  // keeps the select on Tv below the loads above
+      uint32_t next = last ? Tv : nxt;
+      next = next < (uint32_t)(WG * U) ? next : (uint32_t)(WG * U);
       for (uint32_t i = v.y + part; i < next; i += 4) s_map[i] = (uint8_t)c;
     }
   }
+  asm volatile("" : "+v"(Tv));
+  const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tv);
+  bool overflow = overflow_n;
+  int why = overflow ? 1 : 0;  // overflow reason (kept in unit_thr[2u+1] for diagnostics)
+  if (!overflow && T > (uint32_t)(WG * U)) { overflow = true; why = 2; }
   __syncthreads();
   STAMP(1);  // descriptors + map done
 
