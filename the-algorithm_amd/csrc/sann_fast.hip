@@ -171,7 +171,7 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
 }
 __device__ inline uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
 
-constexpr int bloom_log2(int capacity) { return capacity <= 512 ? 8 : capacity <= 1024 ? 9 : capacity <= 2048 ? 10 : 11; }
+constexpr int bloom_log2(int capacity) { return capacity <= 512 ? 8 : capacity <= 1024 ? 9 : capacity <= 1536 ? 10 : 11; }
 
 enum {
   CTL_NFLAG = 0, CTL_NM, CTL_LIVE, CTL_NSURV, CTL_CNT, CTL_SEL_D, CTL_SEL_A, CTL_SEL_B, CTL_BAD, CTL_KMIN, CTL_KMAX,
@@ -185,7 +185,9 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 8 ? 5 : 3)) v
   constexpr int SCAP = FAST_SCAP;
   constexpr int BW = bloom_log2(WG * U);  // log2 of the Bloom filter's 64-bit words
   constexpr int BLOOM_ALLOC = 1 << BW;
-  constexpr int FBLOOM_WORDS = 256;
+  constexpr int HB = 18 + BW;  // hash bits: 3 x 6 bit positions, then the word index
+  constexpr int FBLOOM_WORDS = BW >= 11 ? 128 : 256;  // (the 16 KB Bloom filter leaves room for 128: five workgroups per CU)
+  constexpr int FB = BW >= 11 ? 7 : 8;
   constexpr int MCAP = (WG * U <= 1024) ? 64 : 128;
   __shared__ unsigned long long s_bloom[BLOOM_ALLOC];
   __shared__ uint32_t s_begin[NSCAN_MAX];
@@ -197,9 +199,16 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 8 ? 5 : 3)) v
   __shared__ long long s_Mid[MCAP];
   __shared__ int s_Mseq[MCAP], s_Mrole[MCAP];
   __shared__ double s_Msc[MCAP], s_Mdot[MCAP], s_Mnsq[MCAP];
-  __shared__ long long s_sid[SCAP];
-  __shared__ double s_sdot[SCAP], s_snsq[SCAP];
-  __shared__ unsigned s_hist[256];
+  // The survivor list and the radix histogram are first touched after the duplicate phase, when the Bloom filter is
+  // dead: with a filter of >= 1024 words they live in its memory (barriers at the end of phase 3 lie between).
+  constexpr bool ALIAS = BLOOM_ALLOC >= 3 * SCAP + 128;
+  __shared__ long long s_sid_own[ALIAS ? 1 : SCAP];
+  __shared__ double s_sdot_own[ALIAS ? 1 : SCAP], s_snsq_own[ALIAS ? 1 : SCAP];
+  __shared__ unsigned s_hist_own[ALIAS ? 1 : 256];
+  long long *const s_sid = ALIAS ? reinterpret_cast<long long *>(s_bloom) : s_sid_own;
+  double *const s_sdot = ALIAS ? reinterpret_cast<double *>(s_bloom + SCAP) : s_sdot_own;
+  double *const s_snsq = ALIAS ? reinterpret_cast<double *>(s_bloom + 2 * SCAP) : s_snsq_own;
+  unsigned *const s_hist = ALIAS ? reinterpret_cast<unsigned *>(s_bloom + 3 * SCAP) : s_hist_own;
   __shared__ int s_ctl[CTL_N];
 
   const int tid = threadIdx.x;
@@ -305,13 +314,13 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 8 ? 5 : 3)) v
         live += __popcll(__ballot(keep));  // wave count, identical in all lanes
         if (keep) {
           // ---- 3a. blocked Bloom filter: three bits of one 64-bit word, one atomic ------------
-          const uint32_t hsh = table_hash(id[u], 28);  // 3 x 6 bits positions, then the word index
+          const uint32_t hsh = table_hash(id[u], HB);
           const unsigned long long bits =
               (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63)) | (1ull << ((hsh >> 12) & 63));
-          const unsigned long long old = atomicOr(&s_bloom[hsh >> (28 - BW)], bits);
+          const unsigned long long old = atomicOr(&s_bloom[hsh >> 18], bits);
           if ((old & bits) == bits) {
             // possibly seen before: mark the id's bits in the (sparse) "flagged" filter
-            atomicOr(&s_fbloom[hsh >> 20], bits);
+            atomicOr(&s_fbloom[hsh >> (HB - FB)], bits);
             s_ctl[CTL_NFLAG] = 1;
           }
         }
@@ -332,10 +341,10 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 8 ? 5 : 3)) v
     for (int u = 0; u < U; u++) {
       mi[u] = -1;
       if (seq[u] >= 0) {
-        const uint32_t hsh = table_hash(id[u], 28);
+        const uint32_t hsh = table_hash(id[u], HB);
         const unsigned long long bits =
             (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63)) | (1ull << ((hsh >> 12) & 63));
-        if ((s_fbloom[hsh >> 20] & bits) == bits) {
+        if ((s_fbloom[hsh >> (HB - FB)] & bits) == bits) {
           const int m = atomicAdd(&s_ctl[CTL_NM], 1);
           mi[u] = m;
           if (m < MCAP) {
