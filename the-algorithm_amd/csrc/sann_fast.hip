@@ -531,6 +531,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 8 ? 5 : 3)) v
         kmax = lv && k > kmax ? k : kmax;
       }
     }
+    for (int i = tid; i < 256; i += WG) s_hist[i] = 0;  // for the first histogram pass of phase 5 (the Bloom filter is dead)
     const uint32_t wmin = wave_min_u32(kmin), wmax = wave_max_u32(kmax);
     const bool wbad = __ballot(bad) != 0ull;
     if ((tid & 63) == 0) {
@@ -579,9 +580,11 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 8 ? 5 : 3)) v
       int width = hbit - shift + 1;
       uint32_t prefix = (hbit == 31) ? 0u : (gmax >> (hbit + 1)) << (hbit + 1);
       int need = kl, budget = SCAP;
-      for (;;) {
-        for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
-        __syncthreads();
+      for (bool first = true;; first = false) {
+        if (!first) {  // (the first pass finds the histogram cleared before the barrier that ended phase 4)
+          for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
+          __syncthreads();
+        }
         const uint32_t hi_mask = (shift + width >= 32) ? 0u : (~0u << (shift + width));
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -603,8 +606,8 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 8 ? 5 : 3)) v
           width = shift - ns;
           shift = ns;
         }
+        if (stop) break;  // uniform; nothing below reuses the histogram or these control words
         __syncthreads();
-        if (stop) break;
       }
       tau = prefix;
     }
