@@ -164,8 +164,7 @@ def main():
     K = cfg.maxNumResults
     shard_k = K
     if world > 1:
-        share = K / world
-        shard_k = min(K, int(-(-(share + 6.0 * (share * (1.0 - 1.0 / world)) ** 0.5 + 8.0) // 8) * 8))
+        shard_k = pkg.sharding.shard_list_length(K, world)
     if args.shard_k > 0 and sharded:
         shard_k = min(K, args.shard_k)
     inexact_seen = 0
@@ -202,8 +201,8 @@ def main():
         # them; the owner merges world per-shard lists.  Exchange and owner merge run on a side stream.
         if sharded:
             # one packed message per owner: [ids nql*stride | score bits nql*stride | counts nql | map sizes nql]
+            chunk, _offsets = pkg.sharding.owner_message_layout(nql, stride)  # bytes, a multiple of 8
             arr = nql * stride * 8
-            chunk = 2 * arr + 8 * nql  # bytes, a multiple of 8
             sends = [torch.zeros(world * chunk, dtype=torch.uint8, device="cuda") for _ in range(depth)]
             recv = torch.zeros_like(sends[0])  # [world shards][chunk]: this rank's queries, one chunk per shard
             rp = recv.data_ptr()

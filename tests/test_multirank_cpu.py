@@ -1,9 +1,12 @@
-"""N > 1 path on CPU: two gloo ranks, each owning one tweet-hash shard of a small corpus.
-Every rank answers the whole batch on its shard (here with the oracle standing in for the GPU
-kernels), packs its results with the same layout bench.py uses, one all_gather moves them, and the
-merged top-k must equal the unsharded oracle -- i.e. tweet-hash sharding + ComposedQueryable-style
-merge is exact.  The shard of a tweet comes from the library's own
+"""N > 1 path on CPU: two gloo ranks, each owning one tweet-hash shard of a small corpus and half of the queries.
+Every rank answers the whole batch on its shard (here with the oracle standing in for the GPU kernels) with lists
+cut at `sharding.shard_list_length(k, world)`, packs one message per owner with the layout bench.py binds the merge
+kernel to, the messages are exchanged (all-gather + slice: gloo has no all-to-all; bench.py's rehearsal path does
+the same), and each owner merges the lists of its queries with the numpy restatement of `sann_merge_shards_cut`:
+every answer must be proven by the cut lists and equal the unsharded oracle bit for bit -- i.e. tweet-hash sharding
++ ComposedQueryable-style merge is exact.  The shard of a tweet comes from the library's own
 sann_tweet_shard (a host function; no GPU needed)."""
+import dataclasses
 import os
 import sys
 
@@ -25,12 +28,17 @@ def _worker(rank, world, port, out):
 
     pkg = load_package()
     lib = pkg.load_library()
+    sh_ = pkg.sharding
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         co = pkg.corpus.make_corpus(20000, 800, seed=5, index_cap=300)
-        nq, k, M = 12, 50, 120
+        nq, k, M = 12, 120, 200
+        nql = nq // world
         offs, cids, scs = pkg.corpus.make_queries(nq, 800, seed=6, clusters_per_user=30)
         cfg = pkg.SimClustersANNConfig(maxNumResults=k, maxTopTweetsPerCluster=M, maxScanClusters=30)
+        shard_k = sh_.shard_list_length(k, world)
+        assert shard_k < k  # the lists really are cut
+        cfg_shard = dataclasses.replace(cfg, maxNumResults=shard_k)
         # this rank's shard: the first M postings of every list (global ranks!), then my tweets only
         t_l, s_l, off = [], [], [0]
         for i in range(len(co.cluster_ids)):
@@ -39,24 +47,23 @@ def _worker(rank, world, port, out):
             mine = np.array([lib.sann_tweet_shard(int(x), world) == rank for x in t], bool)
             t_l.append(t[mine]); s_l.append(s[mine]); off.append(off[-1] + int(mine.sum()))
         sh = (co.cluster_ids, np.array(off, np.int64), np.concatenate(t_l), np.concatenate(s_l))
-        ids = np.zeros((nq, k), np.int64); sc = np.zeros((nq, k)); cnt = np.zeros(nq, np.int32); msz = np.zeros(nq, np.int32)
+        ids = np.zeros((nq, shard_k), np.int64); sc = np.zeros((nq, shard_k)); cnt = np.zeros(nq, np.int32); msz = np.zeros(nq, np.int32)
         for q in range(nq):
-            i, s, m = oracle.sann_query(cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]], None, cfg, co.now_ms, *sh)
+            i, s, m = oracle.sann_query(cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]], None, cfg_shard, co.now_ms, *sh)
             ids[q, :len(i)] = i; sc[q, :len(i)] = s; cnt[q] = len(i); msz[q] = m
-        mine = torch.from_numpy(pkg.sharding.pack(ids, sc, cnt, msz))
-        gathered = torch.zeros(world * mine.numel(), dtype=torch.int64)
-        dist.all_gather_into_tensor(gathered, mine)
-        g = gathered.numpy().reshape(world, -1)
+        send = torch.from_numpy(sh_.pack_for_owners(ids, sc, cnt, msz, world))
+        parts = [torch.zeros_like(send) for _ in range(world)]
+        dist.all_gather(parts, send)
+        size = send.numel() // world
+        recv = torch.cat([p[rank * size:(rank + 1) * size] for p in parts]).numpy()  # message r of every shard
+        g_ids, g_sc, g_cnt, g_msz = sh_.unpack_from_shards(recv, world, nql, shard_k)
         ok = True
-        for q in range(nq):
-            cand, total = [], 0
-            for r in range(world):
-                a, b, c, d = pkg.sharding.unpack(g[r], nq, k)
-                cand += list(zip(a[q, :c[q]].tolist(), b[q, :c[q]].tolist())); total += int(d[q])
-            cand.sort(key=lambda x: (-x[1], x[0]))
+        for ql in range(nql):
+            q = rank * nql + ql
+            m_ids, m_sc, proven = sh_.merge_cut_lists(g_ids[:, ql], g_sc[:, ql], g_cnt[:, ql], k, shard_k)
             o_i, o_s, o_m = oracle.sann_query(cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]], None, cfg, co.now_ms,
                                               co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores)
-            ok &= [c[0] for c in cand[:k]] == o_i.tolist() and [c[1] for c in cand[:k]] == o_s.tolist() and total == o_m
+            ok &= proven and m_ids.tolist() == o_i.tolist() and m_sc.tolist() == o_s.tolist() and int(g_msz[:, ql].sum()) == o_m
         out[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -90,3 +97,43 @@ def test_shard_and_partition_hash_are_stable(pkg):
     xs = rng.integers(0, 2**62, 4000)
     counts = np.bincount([lib.sann_tweet_shard(int(x), 8) for x in xs], minlength=8)
     assert counts.min() > 400 and counts.max() < 600
+
+
+def test_shard_list_length_and_owner_messages(pkg):
+    sh = pkg.sharding
+    assert [sh.shard_list_length(400, n) for n in (1, 2, 4, 8)] == [400, 272, 160, 104]
+    assert sh.shard_list_length(10, 8) == 10 and sh.shard_list_length(1000, 8) == 200
+    rng = np.random.default_rng(3)
+    world, nql, stride = 3, 4, 5
+    nq = world * nql
+    ids = rng.integers(-2**62, 2**62, (nq, stride))
+    sc = rng.normal(size=(nq, stride))
+    cnt = rng.integers(0, stride + 1, nq).astype(np.int32)
+    msz = rng.integers(0, 1000, nq).astype(np.int32)
+    size, offsets = sh.owner_message_layout(nql, stride)
+    assert size % 8 == 0 and offsets == (0, nql * stride * 8, 2 * nql * stride * 8, 2 * nql * stride * 8 + 4 * nql)
+    sent = [sh.pack_for_owners(ids + s, sc, cnt, msz + s, world) for s in range(world)]  # three "shards"
+    for r in range(world):  # owner r receives message r of every shard
+        recv = np.concatenate([b[r * size:(r + 1) * size] for b in sent])
+        g_ids, g_sc, g_cnt, g_msz = sh.unpack_from_shards(recv, world, nql, stride)
+        for s in range(world):
+            assert np.array_equal(g_ids[s], ids[r * nql:(r + 1) * nql] + s) and np.array_equal(g_sc[s], sc[r * nql:(r + 1) * nql])
+            assert np.array_equal(g_cnt[s], cnt[r * nql:(r + 1) * nql]) and np.array_equal(g_msz[s], msz[r * nql:(r + 1) * nql] + s)
+
+
+def test_cut_list_merge_proof_rule(pkg):
+    """The owner's proof: a list that arrived full may hide candidates below its last entry."""
+    merge = pkg.sharding.merge_cut_lists
+    ids = np.array([[1, 2, 3], [4, 5, 6]], np.int64)
+    sc = np.array([[9.0, 8.0, 7.0], [6.0, 5.0, 4.0]])
+    # shard 0 arrived full (3 of shard_k = 3) and its last entry (7.0) ranks above the merged 4th (6.0): unproven
+    assert merge(ids, sc, np.array([3, 3]), 4, 3)[2] is False
+    # k = 3: the merged 3rd entry IS shard 0's last one; shard 1's last entry lies below it: proven
+    got = merge(ids, sc, np.array([3, 3]), 3, 3)
+    assert got[0].tolist() == [1, 2, 3] and got[1].tolist() == [9.0, 8.0, 7.0] and got[2] is True
+    # fewer merged entries than k and a full list: unproven; no full list: proven
+    assert merge(ids, sc, np.array([3, 1]), 10, 3)[2] is False
+    assert merge(ids, sc, np.array([2, 1]), 10, 3)[2] is True
+    # equal scores: the smaller tweet id ranks first
+    tie = merge(np.array([[7], [5]], np.int64), np.array([[1.0], [1.0]]), np.array([1, 1]), 1, 4)
+    assert tie[0].tolist() == [5] and tie[2] is True
