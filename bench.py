@@ -167,6 +167,23 @@ def main():
         shard_k = pkg.sharding.shard_list_length(K, world)
     if args.shard_k > 0 and sharded:
         shard_k = min(K, args.shard_k)
+    # streams are made once (a repeated measurement must not add streams: more streams than hardware queues share
+    # queues, and two streams on one queue run in order)
+    depth = 1 if args.no_overlap else max(1, args.inflight)
+    side_stream = None
+    if sharded:
+        t_streams = [torch.cuda.current_stream()] if depth == 1 else [torch.cuda.Stream() for _ in range(depth)]
+        streams = [t.cuda_stream for t in t_streams]
+        side_stream = t_streams[0] if args.no_overlap else torch.cuda.Stream()
+    elif depth == 1:
+        streams = [0]
+    else:
+        hip = ctypes.CDLL("libamdhip64.so")
+        streams = []
+        for _ in range(depth):
+            h_stream = ctypes.c_void_p()
+            assert hip.hipStreamCreateWithFlags(ctypes.byref(h_stream), 1) == 0  # hipStreamNonBlocking
+            streams.append(h_stream.value)
     inexact_seen = 0
     while True:
         cfg_run = cfg if shard_k == K else dataclasses.replace(cfg, maxNumResults=shard_k)
@@ -175,21 +192,8 @@ def main():
         # descriptor / unit kernels run beside batch i's merge kernel (LDS-bound, one round of workgroups), and the
         # host's per-batch stream wait + status check (sann_batch_finish) is off the GPU's critical path.  Every batch
         # is complete (finished, checked, and when sharded exchanged and merged) before the timed region ends.
-        depth = 1 if args.no_overlap else max(1, args.inflight)
         qbs = [pkg.QueryBatch(index, offs, cids, scs, cfg_run, now_ms=now_ms) for _ in range(depth)]
         stride = qbs[0].stride
-        if sharded:
-            t_streams = [torch.cuda.current_stream()] if depth == 1 else [torch.cuda.Stream() for _ in range(depth)]
-            streams = [t.cuda_stream for t in t_streams]
-        elif depth == 1:
-            streams = [0]
-        else:
-            hip = ctypes.CDLL("libamdhip64.so")
-            streams = []
-            for _ in range(depth):
-                h_stream = ctypes.c_void_p()
-                assert hip.hipStreamCreateWithFlags(ctypes.byref(h_stream), 1) == 0  # hipStreamNonBlocking
-                streams.append(h_stream.value)
         launched = []  # slots whose batch is enqueued but not yet finished, oldest first
         n_steps_done = [0]
         alone = [False]  # True: one batch at a time, nothing overlapped (the per-kernel timings after the timed region)
@@ -206,7 +210,6 @@ def main():
             sends = [torch.zeros(world * chunk, dtype=torch.uint8, device="cuda") for _ in range(depth)]
             recv = torch.zeros_like(sends[0])  # [world shards][chunk]: this rank's queries, one chunk per shard
             rp = recv.data_ptr()
-            side_stream = t_streams[0] if args.no_overlap else torch.cuda.Stream()
             sent = [None] * depth  # event: the exchange that read sends[slot] has finished
             ready = [torch.cuda.Event() for _ in sends]  # event: the batch in sends[slot] is final
             for j, qb in enumerate(qbs):
