@@ -286,7 +286,8 @@ def main():
                 assert lib.sann_device_synchronize(local_rank) == 0
 
         def check_sharded_against_unsharded():
-            """Rehearsal only: rank 0 also builds the whole corpus and checks the merged answer of its queries."""
+            """Sharded runs, after the timed region: rank 0 also builds the whole corpus on its GPU and checks the merged
+            answer of the queries it owns, bit for bit (the other ranks wait at the final barrier)."""
             full = pkg.ClusterTweetIndex.synthetic(args.tweets, pkg.corpus.N_CLUSTERS, seed=pkg.corpus.CORPUS_SEED,
                                                    index_cap=2000, now_ms=now_ms, device=local_rank, n_partitions=args.partitions)
             qf = pkg.QueryBatch(full, offs[:nql + 1], cids[:offs[nql]], scs[:offs[nql]], cfg, now_ms=now_ms)
@@ -448,7 +449,7 @@ def main():
         "quality_checked_queries": (min(args.quality_queries, nq) if recall_quality is not None else 0),
         "parity_checked_queries": n_check,
         "fallback_units": n_fallback_units,
-        "sharded_equals_unsharded": check_sharded_against_unsharded() if (world > 1 and args.backend == "gloo") else None,
+        "sharded_equals_unsharded": check_sharded_against_unsharded() if world > 1 else None,
         "roofline": roof,
         "cpu_baseline": cpu,
         "corpus_build_s": t_corpus,
