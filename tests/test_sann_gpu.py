@@ -136,6 +136,21 @@ def test_few_partitions_small_k_merge(pkg, oracle, small, P, k):
     index.close()
 
 
+@pytest.mark.parametrize("P", [8, 32])
+def test_more_cut_values_than_the_cache_holds(pkg, oracle, small, P):
+    """Six distinct maxTopTweetsPerCluster values in one batch: the index caches cut tables for four, the other
+    queries' descriptors are found by binary search in the rank column (both descriptor kernels: one wave per
+    unit at P = 8, one workgroup per query at P = 32)."""
+    co, offs, cids, scs = small
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=P)
+    nq = len(offs) - 1
+    Ms = [3, 17, 60, 150, 333, 10000]
+    cfgs = [pkg.SimClustersANNConfig(maxNumResults=100, maxTopTweetsPerCluster=Ms[q % len(Ms)]) for q in range(nq)]
+    out, _ = run_batch(pkg, index, co, offs, cids, scs, cfgs)
+    check_against_oracle(pkg, oracle, co, offs, cids, scs, cfgs, out)
+    index.close()
+
+
 def test_heavy_duplication_and_explicit_order(pkg, oracle):
     """Every cluster lists the SAME tweets: each candidate is a 40-term ordered fp64 sum, and the
     explicit key order changes last-ulp results (accumulation order is the caller's)."""
