@@ -327,6 +327,7 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
   std::vector<uint64_t> unit_bound((size_t)b->n_units, 0);
   std::vector<double> unit_est((size_t)b->n_units, 0.0);  // expected postings with rank < M
 
+  int max_n_scan = 0;
   for (int32_t q = 0; q < nq; q++) {
     const sann_config_t &cfg = configs[n_configs == 1 ? 0 : q];
     int64_t eb = emb_offsets[q], ee = emb_offsets[q + 1];
@@ -419,6 +420,7 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
       postings_scanned += (int64_t)(ix->n_shards == 1 ? std::min<uint64_t>(whole, (uint64_t)h.M) : bound_sum);
     }
     h.n_scan = (int32_t)b->h_scan_row.size() - h.scan_begin;
+    max_n_scan = std::max(max_n_scan, (int)h.n_scan);
     alg_bytes += (int64_t)h.n_scan * 12;
   }
   // postings_scanned = sum_c min(len_c, M) (SURVEY 8d's P_q) when the shard holds whole lists;
@@ -451,6 +453,7 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
     if (const char *ov = getenv("SANN_UNIT_CAP")) ucap = atoi(ov);  // tuning / test override
     b->fast.unit_capacity = ucap;
     b->fast.k_local = 0;
+    b->fast.max_n_scan = max_n_scan;
     b->cap = FAST_SCAP;  // a fast unit emits at most its survivor list
     const char *force = getenv("SANN_FORCE_GENERAL");
     b->use_fast = !(force && force[0] == '1');
@@ -599,7 +602,7 @@ static int batch_run(sann_batch_t *b, void *hip_stream, bool chained, sann_batch
   } else {
     if (b->profiling && !(b->prof_unit_only && b->use_fast)) HIP_TRY(hipEventRecord(b->ev[0], st));
     if (b->use_fast) {
-      hipError_t e = launch_desc(b->ix->view(), b->view(), b->n_units, st);
+      hipError_t e = launch_desc(b->ix->view(), b->view(), b->n_units, b->fast.max_n_scan, st);
       if (e != hipSuccess) return fail(SANN_EDEVICE, std::string("launch_desc: ") + hipGetErrorString(e));
       // the descriptor kernel may run beside anything; the dominant kernel waits for its predecessor's
       if (after && after != b && after->unit_done_recorded)

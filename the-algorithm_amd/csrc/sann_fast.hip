@@ -693,8 +693,11 @@ static hipError_t launch_one(const IndexView &ix, const BatchView &b, const Fast
 // tables; the per-partition prefix over the clusters runs in LDS, and the rows are written out coalesced.  One
 // round of 1024 workgroups instead of four rounds of one-wave units, each a chain of three dependent trips to memory.
 constexpr int DESC_Q_ITEMS = 4096;  // NSCAN_MAX x 32
-__global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView b) {
-  __shared__ uint32_t s_base[DESC_Q_ITEMS], s_len[DESC_Q_ITEMS];  // [c * P + p]; s_len becomes the exclusive prefix
+__global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView b, int items_cap) {
+  // [c * P + p]; s_len becomes the exclusive prefix.  Sized by the launch for the batch's largest query (12.5 KB at
+  // 50 clusters x 32 partitions): small enough to find room on a CU that is full of unit-kernel workgroups.
+  extern __shared__ uint32_t s_desc[];
+  uint32_t *const s_base = s_desc, *const s_len = s_desc + items_cap;
   const int tid = threadIdx.x;
   const int q = blockIdx.x;
   {
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
 #pragma unroll
   for (int j = 0; j < 4; j++)
     if (b.cut_M[j] == M) cut = b.cut[j];
-  const int n_items = n_scan * P;  // <= DESC_Q_ITEMS
+  const int n_items = n_scan * P;  // <= items_cap
   for (int i = tid; i < n_items; i += 256) {
     const int c = i >> ix.log2P, p = i & (P - 1);
     const int row = b.scan_row[scan_begin + c];
@@ -750,11 +753,12 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
   }
 }
 
-hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, hipStream_t stream) {
+hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int max_n_scan, hipStream_t stream) {
   if (n_units <= 0) return hipSuccess;
+  const int items_cap = ix.P * (max_n_scan < NSCAN_MAX ? (max_n_scan > 0 ? max_n_scan : 1) : NSCAN_MAX);
   // (with fewer than 16 partitions a query has too few sub-lists to occupy a workgroup: 40 us against 33 at P = 8)
   if (ix.P >= 16 && ix.P * NSCAN_MAX <= DESC_Q_ITEMS)
-    hipLaunchKernelGGL(desc_query_kernel, dim3((unsigned)b.nq), dim3(256), 0, stream, ix, b);
+    hipLaunchKernelGGL(desc_query_kernel, dim3((unsigned)b.nq), dim3(256), (size_t)items_cap * 8, stream, ix, b, items_cap);
   else
     hipLaunchKernelGGL(desc_kernel, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, ix, b, n_units);
   return hipGetLastError();
