@@ -171,7 +171,7 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
 }
 __device__ inline uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
 
-constexpr int bloom_log2(int capacity) { return capacity <= 512 ? 8 : capacity <= 1024 ? 9 : capacity <= 1536 ? 10 : 11; }
+constexpr int bloom_log2(int capacity) { return capacity <= 512 ? 8 : capacity <= 1024 ? 9 : 11; }
 
 enum {
   CTL_NFLAG = 0, CTL_NM, CTL_LIVE, CTL_NSURV, CTL_CNT, CTL_SEL_D, CTL_SEL_A, CTL_SEL_B, CTL_BAD, CTL_KMIN, CTL_KMAX,
