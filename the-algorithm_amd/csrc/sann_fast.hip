@@ -181,7 +181,7 @@ enum {
 // second launch bound = waves per SIMD: small units are asked to fit 8 waves (<= 64 VGPRs); the
 // rare duplicate-resolution code may spill, the common path does not
 template <int WG, int U>
-__global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 8 ? 5 : 3)) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
+__global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 8 ? 5 : 3)) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
   constexpr int SCAP = FAST_SCAP;
   constexpr int BW = bloom_log2(WG * U);  // log2 of the Bloom filter's 64-bit words
   constexpr int BLOOM_ALLOC = 1 << BW;
