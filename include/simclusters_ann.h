@@ -117,9 +117,11 @@ const char *sann_version(void);
  * ReadableStore[ClusterId, Seq[(TweetId, Double)]] returns them
  * (simclusters-ann/.../modules/ClusterTweetIndexProviderModule.scala:34-94 over
  *  src/scala/com/twitter/simclusters_v2/summingbird/stores/TopKTweetsForClusterReadableStore.scala:211-229):
- * each list already filtered to score > 0, sorted by score descending and capped.  The order
- * inside a list is kept as given (position i is the `i` of ApproximateCosineSimilarity.scala:87).
- * Tweet ids must be unique inside one list (they are keys of a Map in the store).
+ * each list already filtered to score > 0, sorted by score descending and capped (raw, unsorted postings go
+ * through sann_index_build_from_postings, which applies that contract on the device).  The order inside a list
+ * is kept as given (position i is the `i` of ApproximateCosineSimilarity.scala:87); the operator itself needs
+ * neither order nor sign.  Tweet ids must be unique inside one list (they are keys of a Map in the store):
+ * a repeated id is refused with SANN_EINVAL.
  *   cluster_ids[n_lists]      ascending, unique
  *   list_offsets[n_lists + 1] CSR offsets into tweet_ids / scores
  */
@@ -294,6 +296,13 @@ int sann_batch_device_k(sann_batch_t *batch, void **d_k);
  * fp64 division / sqrt / log with the host bit for bit. */
 int sann_debug_normalise(int32_t device, int32_t alg, int32_t n, const double *dot, const double *nsq, double l2norm,
                          double lognorm, double *out);
+
+/* Audit hook: the fp32 pre-filter score the fast unit kernel gives a single-cluster candidate (posting score s[i],
+ * cluster weight w[i]) under `alg`, by the same device function; out_forced[i] = 1 where the exact score is +inf / NaN
+ * and the candidate is kept unconditionally.  *eps receives the bound the kernel's cut assumes on
+ * |approx / exact - 1| (exact = ApproximateCosineSimilarity.scala:111-119).  Host arrays in and out. */
+int sann_debug_approx(int32_t device, int32_t alg, int32_t n, const double *s, const double *w, double l2norm,
+                      double lognorm, float *out, uint8_t *out_forced, double *eps);
 
 #ifdef __cplusplus
 }

@@ -192,6 +192,23 @@ int sann_index_build(const sann_index_options_t *opts, int32_t n_lists, const in
     }
   }
   ix->max_list_len = max_len;
+  // Tweet ids are keys of a Map in the store (TopKTweetsWithScores.topTweetsByFavClusterNormalizedScore): a list
+  // cannot hold one twice, and the duplicate resolver of the unit kernel relies on it (one posting per tweet and
+  // scanned cluster).  Checked here rather than trusted; order and sign of the scores are the caller's business
+  // (position i is kept as given: ApproximateCosineSimilarity.scala:87 reads lists as they come).
+  {
+    std::vector<int64_t> tmp;
+    for (int32_t r = 0; r < n_lists; r++) {
+      const int64_t b = list_offsets[r], e = list_offsets[r + 1];
+      if (e - b < 2) continue;
+      tmp.assign(tweet_ids + b, tweet_ids + e);
+      std::sort(tmp.begin(), tmp.end());
+      if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end()) {
+        delete ix;
+        return fail(SANN_EINVAL, "cluster " + std::to_string(cluster_ids[r]) + ": a tweet id appears twice in one list");
+      }
+    }
+  }
   uint64_t run = 0;
   ix->h_sub_offsets.resize((size_t)n_lists * P + 1);
   for (size_t i = 0; i < (size_t)n_lists * P; i++) {
@@ -944,6 +961,25 @@ int sann_merge_shards_cut(int32_t device, void *hip_stream, int32_t n_shards, in
                               (const int32_t *)d_counts, (const int32_t *)d_map_sizes, nullptr, k, shard_k, out_stride,
                               (int64_t *)d_out_ids, (double *)d_out_scores, (int32_t *)d_out_counts,
                               (int32_t *)d_out_map_sizes, (int32_t *)d_inexact_count, (hipStream_t)hip_stream));
+  return SANN_OK;
+}
+
+int sann_debug_approx(int32_t device, int32_t alg, int32_t n, const double *s, const double *w, double l2norm,
+                      double lognorm, float *out, uint8_t *out_forced, double *eps) {
+  if (eps) *eps = kApproxEps;
+  if (n < 0 || (n > 0 && (!s || !w || !out || !out_forced))) return fail(SANN_EINVAL, "bad arguments");
+  if (n == 0) return SANN_OK;
+  HIP_TRY(hipSetDevice(device));
+  DevBuf a, b, c, d;
+  HIP_TRY(a.alloc((size_t)n * 8));
+  HIP_TRY(b.alloc((size_t)n * 8));
+  HIP_TRY(c.alloc((size_t)n * 4));
+  HIP_TRY(d.alloc((size_t)n));
+  HIP_TRY(hipMemcpy(a.p, s, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b.p, w, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(launch_debug_approx(alg, n, a.as<double>(), b.as<double>(), l2norm, lognorm, c.as<float>(), d.as<uint8_t>(), nullptr));
+  HIP_TRY(hipMemcpy(out, c.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_forced, d.p, (size_t)n, hipMemcpyDeviceToHost));
   return SANN_OK;
 }
 

@@ -63,6 +63,35 @@ __device__ inline double normalise_f(int alg, double dot, double nsq, double l2n
   }
 }
 
+// The fp32 pre-filter score of phase 4.  |approx / exact - 1| <= APPROX_EPS for every input it does not flag
+// (checked over a wide sweep by tests/test_sann_gpu.py::test_prefilter_error_bound through sann_debug_approx).
+//   nsq64   the candidate's fp64 sum of squares, read only for LogCosine below 1e-6: the exact form is
+//           log(1 + nsq) with 1 + nsq ROUNDED to fp64 (ApproximateCosineSimilarity.scala:113), so for small nsq the
+//           rounding of that sum -- not nsq -- decides the score (1 + nsq == 1 below 1.1e-16: log 0, score +inf).
+//           x = (1 + nsq) - 1 is that rounded excess, exactly; log(1 + x) = x - x^2/2 + O(x^3).
+//   *forced the exact score is +inf (or NaN): the candidate must survive the cut whatever tau is.
+__device__ inline float approx_score(int alg, float d32, float n32, double nsq64, float invl2, float invln, bool *forced) {
+  *forced = false;
+  switch (alg) {
+    case 2: return d32 * invl2 * __builtin_amdgcn_rsqf(n32);
+    case 4: return d32 * __builtin_amdgcn_rsqf(n32);
+    case 3: {
+      float l;
+      if (n32 >= 1e-6f) {
+        l = log1pf(n32);
+      } else {
+        const float x = (float)((1.0 + nsq64) - 1.0);
+        *forced = !(x > 0.f);
+        l = x - 0.5f * x * x;
+      }
+      return d32 * invln * __builtin_amdgcn_rcpf(l);
+    }
+    case 1: return d32;
+    default: return 0.f;
+  }
+}
+constexpr uint32_t FORCED_KEY = 0xff7fffffu;  // FLT_MAX: above every key the range check below lets through
+
 __device__ inline int lower_bound_rank(const uint32_t *a, int n, uint32_t v) {
   int lo = 0, hi = n;
   while (lo < hi) {
@@ -507,25 +536,22 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
       if ((uint32_t)(u * WG) < T && !overflow) {
         const bool lv = seq[u] >= 0;
         float d32, n32;
+        double nsq64;
         if (lv && (seq[u] & 0x10000)) {
+          nsq64 = s_Mnsq[seq[u] & 0xffff];
           d32 = (float)s_Mdot[seq[u] & 0xffff];
-          n32 = (float)s_Mnsq[seq[u] & 0xffff];
+          n32 = (float)nsq64;
         } else {
           const float s32 = (float)sc[u];
+          nsq64 = sc[u] * sc[u];
           d32 = s32 * s_w32[lv ? (seq[u] & 0xffff) : 0];
           n32 = s32 * s32;
         }
-        float a;
-        switch (h.alg) {
-          case 2: a = d32 * invl2 * __builtin_amdgcn_rsqf(n32); break;
-          case 4: a = d32 * __builtin_amdgcn_rsqf(n32); break;
-          case 3: a = d32 * invln * __builtin_amdgcn_rcpf(log1pf(n32)); break;
-          case 1: a = d32; break;
-          default: a = 0.f; break;
-        }
+        bool forced;
+        const float a = approx_score(h.alg, d32, n32, nsq64, invl2, invln, &forced);
         // the fp32 shortcut is only trusted for ordinary positive magnitudes
-        bad = bad || (lv && !(a > 1e-30f && a < 1e30f && n32 > 1e-30f && n32 < 1e30f));
-        const uint32_t k = lv ? (__float_as_uint(a) | 0x80000000u) : 0u;
+        bad = bad || (lv && !forced && !(a > 1e-30f && a < 1e30f && n32 > 1e-30f && n32 < 1e30f));
+        const uint32_t k = lv ? (forced ? FORCED_KEY : (__float_as_uint(a) | 0x80000000u)) : 0u;
         k32[u] = k;
         kmin = lv && k < kmin ? k : kmin;
         kmax = lv && k > kmax ? k : kmax;
@@ -650,8 +676,11 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
   const int ns = s_ctl[CTL_NSURV] < SCAP ? s_ctl[CTL_NSURV] : SCAP;
   // theta: every candidate below the cut has approx < tau, hence exact < tau * (1 + 2 EPS)
   unsigned long long theta_key = 0ull;
-  if (tau != 0u) {
-    const double tau_val = (double)__uint_as_float(tau & 0x7fffffffu);
+  // ... unless every live candidate survived the cut (tau can be non-zero and still below all of them when the
+  // need-th key sits in the lowest occupied digit): then nothing is withheld and nothing may be dropped below.
+  if (tau != 0u && s_ctl[CTL_NSURV] < n_live) {
+    double tau_val = (double)__uint_as_float(tau & 0x7fffffffu);
+    tau_val = tau_val < 1e30 ? tau_val : 1e30;  // a cut inside the forced (+inf) band: the others are still < 1e30
     theta_key = score_key(tau_val * (1.0 + 2.0 * (double)APPROX_EPS));
   }
 
@@ -761,6 +790,26 @@ hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int
     hipLaunchKernelGGL(desc_query_kernel, dim3((unsigned)b.nq), dim3(256), (size_t)items_cap * 8, stream, ix, b, items_cap);
   else
     hipLaunchKernelGGL(desc_kernel, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, ix, b, n_units);
+  return hipGetLastError();
+}
+
+// Audit hook: the pre-filter's approximate score of a single-cluster candidate (posting score s, cluster weight w),
+// computed by the very function the unit kernel calls, with the unit kernel's fp32 conversions.
+__global__ void debug_approx_kernel(int alg, int n, const double *s, const double *w, double l2norm, double lognorm,
+                                    float *out, uint8_t *out_forced) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float invl2 = (float)(1.0 / l2norm), invln = (float)(1.0 / lognorm);
+  const float s32 = (float)s[i];
+  bool forced;
+  out[i] = approx_score(alg, s32 * (float)w[i], s32 * s32, s[i] * s[i], invl2, invln, &forced);
+  out_forced[i] = forced ? 1 : 0;
+}
+hipError_t launch_debug_approx(int alg, int n, const double *s, const double *w, double l2norm, double lognorm, float *out,
+                               uint8_t *out_forced, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(debug_approx_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, alg, n, s, w, l2norm, lognorm, out,
+                     out_forced);
   return hipGetLastError();
 }
 

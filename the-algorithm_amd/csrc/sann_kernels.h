@@ -18,6 +18,10 @@ hipError_t launch_merge_shards(int n_shards, int nq, int stride, int64_t pitch, 
 hipError_t launch_debug_normalise(int alg, int n, const double *dot, const double *nsq, double l2norm, double lognorm,
                                   double *out, hipStream_t stream);
 
+hipError_t launch_debug_approx(int alg, int n, const double *s, const double *w, double l2norm, double lognorm, float *out,
+                               uint8_t *out_forced, hipStream_t stream);
+constexpr double kApproxEps = 4e-6;  // = APPROX_EPS of sann_fast.hip, reported by sann_debug_approx
+
 // LDS fast path (sann_fast.hip).  Returns hipErrorInvalidValue when the configuration cannot
 // run on the fast path at all (the caller then uses the general path for every unit).
 constexpr int FAST_SCAP = 160;  // candidates a fast unit examines exactly and may emit (BatchView.cap)
