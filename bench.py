@@ -75,6 +75,11 @@ def main():
                     help="batches in flight, but a batch's unit kernel waits for the previous batch's merge kernel (only the descriptor kernel and the host overlap)")
     ap.add_argument("--no-overlap", action="store_true", help="one batch at a time on one stream (and, sharded, exchange and owner merge on that stream too)")
     ap.add_argument("--shard-k", type=int, default=0, help="override the per-shard list length of sharded runs (0 = k/N + 6 sigma + 8)")
+    ap.add_argument("--e2e-steps", type=int, default=-1,
+                    help="steps of the end-to-end leg: fresh queries every step through sann_get_tweet_candidates, host buffers in "
+                         "and out (N = 1 only; -1 = as many as --steps, 0 = skip)")
+    ap.add_argument("--e2e-threads", type=int, default=3, help="concurrent callers of the end-to-end leg (the reference's callers are Finagle worker threads)")
+    ap.add_argument("--e2e-query-sets", type=int, default=4, help="distinct query batches the end-to-end leg rotates through")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cpu_count, 16))")
     args = ap.parse_args()
     if args.workload != "sann":
@@ -354,6 +359,69 @@ def main():
         break
     value = candidates_per_step * args.steps / elapsed
 
+    # ---- end-to-end leg: the boundary call itself, fresh queries every step ---------------------------------------
+    # sann_get_tweet_candidates = host arrays in -> packed H2D -> device-side query preparation -> descriptor / unit /
+    # merge kernels -> D2H of the results into (pinned) host arrays, from --e2e-threads concurrent callers, each with
+    # its own pooled batch object and stream.  Reported beside `value`, never instead of it: PCIe-inclusive.
+    e2e = None
+    n_e2e = args.steps if args.e2e_steps < 0 else args.e2e_steps
+    if not sharded and n_e2e > 0:
+        import threading
+
+        sa = pkg.simclusters_ann
+        n_sets = max(1, args.e2e_query_sets)
+        qsets = [(offs, cids, scs)]
+        o_all, c_all, s_all = pkg.corpus.make_queries(nq * (n_sets - 1), seed=pkg.corpus.QUERY_SEED + 1) if n_sets > 1 else (None, None, None)
+        for i in range(n_sets - 1):
+            lo, hi = o_all[i * nq], o_all[(i + 1) * nq]
+            qsets.append((o_all[i * nq:(i + 1) * nq + 1] - lo, c_all[lo:hi], s_all[lo:hi]))
+        n_thr = max(1, args.e2e_threads)
+        outs = [(sa.pinned_array((nq, K), np.int64), sa.pinned_array((nq, K), np.float64), sa.pinned_array((nq,), np.int32),
+                 sa.pinned_array((nq,), np.int32)) for _ in range(n_thr)]
+        cand_total = [0] * n_thr
+        first_answer = [None]
+
+        def caller(t, steps, record):
+            for i in range(steps):
+                qs = qsets[(t + i * n_thr) % n_sets]
+                ids_e, sc_e, cnt_e, msz_e = sa.get_tweet_candidates(index, *qs, cfg, now_ms=now_ms, out=outs[t])
+                if record:
+                    cand_total[t] += int(cnt_e.sum())
+                    if t == 0 and i == 0:
+                        first_answer[0] = (ids_e.copy(), sc_e.copy(), cnt_e.copy(), msz_e.copy())
+
+        def run_callers(total_steps, record):
+            per = [total_steps // n_thr + (1 if t < total_steps % n_thr else 0) for t in range(n_thr)]
+            ths = [threading.Thread(target=caller, args=(t, per[t], record)) for t in range(n_thr)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+
+        run_callers(max(args.warmup, n_thr), False)
+        assert lib.sann_device_synchronize(local_rank) == 0
+        t0 = time.perf_counter()
+        run_callers(n_e2e, True)
+        assert lib.sann_device_synchronize(local_rank) == 0
+        e2e_elapsed = time.perf_counter() - t0
+        # thread 0's first call answered query set 0 = the replayed batch: must be the same answer, bit for bit
+        fa = first_answer[0]
+        same = bool(np.array_equal(fa[2], counts) and np.array_equal(fa[3], msz) and
+                    all(np.array_equal(fa[0][q, :counts[q]], ids[q, :counts[q]]) and
+                        np.array_equal(fa[1][q, :counts[q]].view(np.int64), scores[q, :counts[q]].view(np.int64)) for q in range(nq)))
+        # one caller alone: the latency of a single call
+        t1 = time.perf_counter()
+        n_lat = max(3, min(10, n_e2e))
+        for i in range(n_lat):
+            sa.get_tweet_candidates(index, *qsets[i % n_sets], cfg, now_ms=now_ms, out=outs[0])
+        lat_ms = (time.perf_counter() - t1) / n_lat * 1e3
+        e2e = {"value": sum(cand_total) / e2e_elapsed, "unit": "candidates/sec", "ms_per_step": e2e_elapsed / n_e2e * 1e3,
+               "steps": n_e2e, "callers": n_thr, "fresh_query_sets": n_sets, "single_call_latency_ms": lat_ms,
+               "equals_replayed_batch": same, "ratio_to_replay_step": (e2e_elapsed / n_e2e) / (elapsed / args.steps),
+               "what": "sann_get_tweet_candidates per step: pageable host query arrays in, packed H2D, device-side query "
+                       "preparation, descriptor + unit + merge kernels, D2H of ids/scores/counts into pinned host arrays; "
+                       "pooled batch objects, no allocation in steady state"}
+
     if rank != 0:
         if sharded:
             dist.barrier()
@@ -451,6 +519,7 @@ def main():
         "fallback_units": n_fallback_units,
         "sharded_equals_unsharded": check_sharded_against_unsharded() if world > 1 else None,
         "roofline": roof,
+        "end_to_end": e2e,
         "cpu_baseline": cpu,
         "corpus_build_s": t_corpus,
     }

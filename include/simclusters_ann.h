@@ -105,7 +105,7 @@ typedef struct sann_batch_stats {
   int32_t n_units;           /* (query, partition) work units launched */
   int32_t n_fallback_units;  /* units re-run on the general (global-memory) path */
   int32_t n_requeried;       /* queries whose first-pass top-k could not be proven exact */
-  int32_t reserved;
+  int32_t max_unit_postings; /* largest number of postings one (query, partition) unit scanned (0 = not measured) */
 } sann_batch_stats_t;
 
 const char *sann_last_error(void);
@@ -189,6 +189,22 @@ int sann_batch_create(sann_index_t *index, int32_t variant, int64_t now_ms, int3
                       const int64_t *source_tweet_ids, const uint8_t *has_source_tweet,
                       const sann_config_t *configs, int32_t n_configs, const int64_t *scan_offsets,
                       const int32_t *scan_cluster_ids, sann_batch_t **out);
+/*
+ * Re-prepare an existing batch object for nq NEW queries (arguments as for sann_batch_create) and enqueue on
+ * `hip_stream` whatever the preparation needs on the device.  The object's device buffers and pinned staging memory are
+ * kept and only grow, so a front end that holds a few batch objects and resets them per request allocates nothing
+ * in steady state.  The queries are prepared ON THE DEVICE (sann_prep.hip: SimClustersEmbedding constructor, norms,
+ * truncate(maxScanClusters), contains / getOrElse, cluster -> index row, age window): the host does one O(nq) pass
+ * over the arguments and one packed H2D copy.  (Embeddings of more than 1024 entries, SANN_HOST_PREP=1 and
+ * SANN_FORCE_GENERAL=1 take the host preparation, which is the same arithmetic.)
+ * Asynchronous; the caller's arrays may be reused as soon as it returns.  The batch must not be in flight
+ * (sann_batch_finish has returned for its previous run), and sann_batch_run has to follow on the same stream.
+ * sann_batch_stats reports postings_scanned / algorithmic_bytes of such a batch once sann_batch_finish has returned.
+ */
+int sann_batch_reset(sann_batch_t *batch, void *hip_stream, int64_t now_ms, int32_t nq, const int64_t *emb_offsets,
+                     const int32_t *emb_cluster_ids, const double *emb_scores, const int64_t *source_tweet_ids,
+                     const uint8_t *has_source_tweet, const sann_config_t *configs, int32_t n_configs,
+                     const int64_t *scan_offsets, const int32_t *scan_cluster_ids);
 /* Enqueue the batch on `hip_stream` (a hipStream_t, NULL = the null stream). Asynchronous;
  * may be called repeatedly (results are overwritten). */
 int sann_batch_run(sann_batch_t *batch, void *hip_stream);
@@ -237,7 +253,9 @@ int32_t sann_tweet_partition(int64_t tweet_id, int32_t n_partitions);
 int sann_device_synchronize(int32_t device);
 int sann_batch_destroy(sann_batch_t *batch);
 
-/* One call = create + run + finish + results + destroy: the shape a JNI stub binds. */
+/* One call = reset + run + finish + results on a batch object from the index's pool (one per concurrent caller, each
+ * with a stream of its own; nothing is allocated in steady state): the shape a JNI stub binds.  Thread-safe.
+ * The output arrays are copied at PCIe speed when they live in pinned memory (sann_host_alloc). */
 int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_ms, int32_t nq,
                               const int64_t *emb_offsets, const int32_t *emb_cluster_ids,
                               const double *emb_scores, const int64_t *source_tweet_ids,
@@ -245,6 +263,11 @@ int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_
                               int32_t n_configs, const int64_t *scan_offsets, const int32_t *scan_cluster_ids,
                               int64_t *out_ids, double *out_scores, int32_t out_stride, int32_t *out_counts,
                               int32_t *out_map_sizes);
+
+/* Pinned (page-locked) host memory for request / response buffers a shim keeps across calls (e.g. behind a direct
+ * ByteBuffer): device copies to and from it run at PCIe speed instead of being staged through the runtime. */
+int sann_host_alloc(int64_t bytes, void **out);
+int sann_host_free(void *p);
 
 /*
  * Merge per-shard results on the device: the `ComposedQueryable` pattern

@@ -511,9 +511,12 @@ def test_fast_path_falls_back_when_units_do_not_fit(pkg, oracle, small):
     index.close()
 
 
-def test_skewed_partition_forces_requery(pkg, oracle):
+def test_skewed_partition_forces_requery(pkg, oracle, monkeypatch):
     """All high scorers hash to ONE partition: that unit truncates its list, the merge cannot
-    prove the top-k exact, the query is re-run on the general path.  Still bit-exact."""
+    prove the top-k exact, the query is re-run on the general path.  Still bit-exact.
+    (The unit geometry is pinned to 1024 postings: a batch prepared on the device sizes its units for uniformly hashed
+    tweets, and this adversarial unit -- 600 postings of one list in one partition -- would simply overflow to the
+    general path on its own, which the second half checks.)"""
     P = 32
     rng = np.random.default_rng(31)
     hot, cold = [], []
@@ -541,10 +544,15 @@ def test_skewed_partition_forces_requery(pkg, oracle):
     scs = np.array([10.0, 1.0, 1.0])
     cfg = pkg.SimClustersANNConfig(maxNumResults=400, maxTopTweetsPerCluster=2000, maxTweetCandidateAgeHours=175200,
                                    annAlgorithm=pkg.ScoringAlgorithm.DotProduct)
+    monkeypatch.setenv("SANN_UNIT_CAP", "1024")
     out, st = run_batch(pkg, index, Co, offs, cids, scs, cfg)
     check_against_oracle(pkg, oracle, Co, offs, cids, scs, cfg, out)
     assert set(out[0][0, :400].tolist()) <= set(hot)
     assert st.n_requeried == 1 and st.n_fallback_units == P
+    monkeypatch.delenv("SANN_UNIT_CAP")
+    out, st = run_batch(pkg, index, Co, offs, cids, scs, cfg)
+    check_against_oracle(pkg, oracle, Co, offs, cids, scs, cfg, out)
+    assert st.n_requeried == 0 and st.n_fallback_units == 1 and st.max_unit_postings >= 600
     index.close()
 
 

@@ -59,15 +59,161 @@ uint32_t next_pow2_u32(uint64_t x) {
 
 }  // namespace
 
+namespace {
+
+// Pinned host memory that only grows.
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  PinBuf() = default;
+  PinBuf(const PinBuf &) = delete;
+  PinBuf &operator=(const PinBuf &) = delete;
+  ~PinBuf() { if (p) (void)hipHostFree(p); }
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = n + n / 4 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+};
+
+// One query prepared on the host: the reference's per-request work before the hot loop, in its order.  Used for
+// embeddings longer than the device path takes, under SANN_HOST_PREP=1 / SANN_FORCE_GENERAL=1, and -- for the
+// queries the fast path could not settle -- to size the general path's tables (unit_bound).
+struct HostQuery {
+  QueryHdr h{};
+  std::vector<int32_t> rows;
+  std::vector<double> w;
+  std::vector<uint64_t> unit_bound;  // [P] postings the unit can scan, at most
+  std::vector<double> unit_est, unit_var;  // [P] expected postings with rank < M, and the variance of that count
+  int64_t postings_scanned = 0;
+};
+
+struct IdScore { int32_t id; double score; };
+
+int prepare_query_host(const sann_index *ix, int variant, int64_t now_ms, const sann_config_t &cfg, const int32_t *cids,
+                       const double *scores, int64_t n_emb, bool has_src, int64_t src_id, const int32_t *scan, int64_t n_scan_keys,
+                       HostQuery &out, std::vector<IdScore> &emb, std::vector<IdScore> &by_id, std::vector<int32_t> &keys) {
+  // SimClustersEmbedding constructor: drop score <= 0, order by (score desc, cluster id asc)
+  emb.clear();
+  for (int64_t i = 0; i < n_emb; i++)
+    if (scores[i] > 0.0) emb.push_back({cids[i], scores[i]});
+  std::sort(emb.begin(), emb.end(), [](const IdScore &x, const IdScore &y) {
+    int c = java_double_compare(y.score, x.score);
+    if (c) return c < 0;
+    return x.id < y.id;
+  });
+  by_id = emb;
+  std::stable_sort(by_id.begin(), by_id.end(), [](const IdScore &x, const IdScore &y) { return x.id < y.id; });
+  // CosineSimilarityUtil.sumOfSquaresArray over sortedScores (left fold)
+  double sumsq = 0.0;
+  for (const IdScore &x : by_id) sumsq = sumsq + x.score * x.score;
+
+  QueryHdr &h = out.h;
+  h.l2norm = std::sqrt(sumsq);
+  h.lognorm = strict_log(sumsq + 1);
+  h.min_score = cfg.min_score;
+  if (variant == SANN_VARIANT_LEGACY) {
+    // SimClustersANNCandidateSource.scala:160-180: the "log" form divides by l2norm, nothing is
+    // filtered by minScore, and there is no cap below maxNumResults
+    h.lognorm = h.l2norm;
+    h.min_score = -std::numeric_limits<double>::infinity();
+  }
+  h.M = cfg.max_top_tweets_per_cluster < 0 ? 0 : cfg.max_top_tweets_per_cluster;
+  int k = cfg.max_num_results < 1000 ? cfg.max_num_results : 1000;
+  h.k = k < 0 ? 0 : k;
+  h.alg = cfg.ann_algorithm;
+  // age window (ApproximateCosineSimilarity.scala:65-72)
+  h.earliest = (cfg.max_tweet_candidate_age_hours >= 175200 && variant != SANN_VARIANT_LEGACY)
+                   ? 0
+                   : snowflake_first_id_for(now_ms - (int64_t)cfg.max_tweet_candidate_age_hours * 3600000ll);
+  h.latest = snowflake_first_id_for(now_ms - (int64_t)cfg.min_tweet_candidate_age_hours * 3600000ll);
+  // source-tweet exclusion (:90 ; Optimized :56,:67 ; Experimental :59,:70)
+  if (variant == SANN_VARIANT_ORIGINAL || variant == SANN_VARIANT_LEGACY) {
+    h.excl_enabled = has_src ? 1 : 0;
+    h.src_excl = has_src ? src_id : 0;
+  } else {
+    h.excl_enabled = 1;
+    h.src_excl = has_src ? src_id : 0;
+  }
+
+  // keys of clusterTweetsMap in accumulation order
+  keys.clear();
+  if (n_scan_keys >= 0) {
+    keys.assign(scan, scan + n_scan_keys);
+  } else {
+    // truncate(maxScanClusters).getClusterIds().toSet -> ascending cluster id
+    int64_t n = cfg.max_scan_clusters < 0 ? 0 : std::min<int64_t>((int64_t)emb.size(), cfg.max_scan_clusters);
+    for (int64_t i = 0; i < n; i++) keys.push_back(emb[(size_t)i].id);
+    std::sort(keys.begin(), keys.end());
+  }
+  const int P = ix->P;
+  out.rows.clear();
+  out.w.clear();
+  out.unit_bound.assign((size_t)P, 0);
+  out.unit_est.assign((size_t)P, 0.0);
+  out.unit_var.assign((size_t)P, 0.0);
+  out.postings_scanned = 0;
+  for (int32_t cluster : keys) {
+    auto it = std::lower_bound(by_id.begin(), by_id.end(), cluster, [](const IdScore &x, int32_t c) { return x.id < c; });
+    bool contained = it != by_id.end() && it->id == cluster;
+    if (!contained && variant != SANN_VARIANT_EXPERIMENTAL) continue;  // `if sourceEmbedding.contains(clusterId)`
+    double w = contained ? it->score : 0.0;                             // getOrElse(clusterId)
+    int row = ix->row_of(cluster);
+    if (row < 0) continue;  // None in clusterTweetsMap
+    out.rows.push_back(row);
+    out.w.push_back(w);
+    uint64_t bound_sum = 0;
+    const uint64_t whole = ix->h_sub_offsets[(size_t)(row + 1) * P] - ix->h_sub_offsets[(size_t)row * P];
+    // share of the list with rank < M, as if this shard held 1/n_shards of every list
+    const double frac = whole == 0 ? 0.0 : std::min(1.0, (double)h.M / ((double)whole * ix->n_shards));
+    for (int p = 0; p < P; p++) {
+      uint64_t len = ix->h_sub_offsets[(size_t)row * P + p + 1] - ix->h_sub_offsets[(size_t)row * P + p];
+      uint64_t lim = std::min<uint64_t>(len, (uint64_t)h.M);
+      out.unit_bound[(size_t)p] += lim;
+      out.unit_est[(size_t)p] += (double)len * frac;
+      out.unit_var[(size_t)p] += (double)len * frac * (1.0 - frac);  // each posting has rank < M with prob. frac
+      bound_sum += lim;
+    }
+    // exact when this shard holds whole lists: min(len_c, M) postings have rank < M
+    out.postings_scanned += (int64_t)(ix->n_shards == 1 ? std::min<uint64_t>(whole, (uint64_t)h.M) : bound_sum);
+  }
+  h.n_scan = (int32_t)out.rows.size();
+  return SANN_OK;
+}
+
+// smallest fast-path geometry (postings a unit holds in registers) with room for `need` postings
+int geometry_for(double need) {
+  static const int kCaps[] = {256, 512, 768, 1024, 1536, 2048, 3072, 4096};  // workgroup size x postings per thread
+  for (int c : kCaps)
+    if ((double)c - 16.0 >= need) return c;
+  return 4096;
+}
+
+}  // namespace
+
 struct sann_batch {
   sann_index *ix = nullptr;
   int nq = 0, variant = 0, cap = 0, stride = 0, n_units = 0;
+  int64_t now_ms = 0;
+  bool device_prep = false;  // the batch was prepared by prep_kernel; the host keeps only the packed inputs
+  // ---- packed copy of the caller's arrays (pinned): what the device path uploads, and what the slow tail re-reads
+  PinBuf stage;
+  DevBuf d_stage;
+  struct StageLayout {
+    size_t emb_offsets = 0, src_ids = 0, scan_offsets = 0, emb_scores = 0, emb_cids = 0, scan_cids = 0, configs = 0,
+           scan_begin = 0, has_src = 0, bytes = 0;
+    bool has_scan = false, has_sources = false;
+    int32_t n_configs = 0;
+  } lay;
+  // ---- host-prepared form (host path only)
   std::vector<QueryHdr> h_hdr;
   std::vector<int32_t> h_scan_row;
   std::vector<double> h_scan_w;
   std::vector<int32_t> h_k;
-  DevBuf hdr, scan_row, scan_w, scan_q, desc, unit_T, d_k;
-  std::vector<int32_t> h_scan_q;
+  DevBuf hdr, scan_row, scan_w, desc, unit_T, d_k, q_stat;
   DevBuf cand_key, cand_id, cand_cnt, unit_unique, unit_flags, unit_fb, unit_thr, status, overflow_units;
   DevBuf out_ids, out_scores, out_counts, out_map_sizes, prof;
   // caller-bound output buffers (NULL = the batch's own)
@@ -79,7 +225,7 @@ struct sann_batch {
   bool unit_done_recorded = false;
   int64_t bound_chunk_pitch = 0;
   // general path: workspace and candidate lists for the units it (re)runs, grown on demand
-  std::vector<uint32_t> unit_bound;  // upper bound on the postings a unit can scan
+  std::vector<uint32_t> unit_bound;  // upper bound on the postings a unit can scan (host path; device path: on demand)
   int cap2 = 1;
   DevBuf cand_key2, cand_id2, g_units, g_off, g_slots, g_keys, g_dot, g_nsq, g_queries;
   int g_cap_units = 0;        // units the g_* / cand_*2 buffers can hold
@@ -87,10 +233,14 @@ struct sann_batch {
   const uint32_t *cut_ptr[4] = {nullptr, nullptr, nullptr, nullptr};  // cached cut tables for up to 4 values of M
   int32_t cut_M[4] = {-1, -1, -1, -1};
   int32_t *h_status = nullptr;  // pinned: [0] overflow units, [1] inexact queries
+  PinBuf h_qstat;               // pinned copy of q_stat (device path)
+  bool qstat_pending = false;
+  int64_t alg_bytes_host = 0;   // host path: n_scan * 12 summed over queries
   bool use_fast = false;
   FastParams fast{};
   sann_batch_stats_t stats{};
   bool ran = false;
+  hipStream_t own_stream = nullptr;  // pooled batches (sann_get_tweet_candidates) run on a stream of their own
   // optional HIP-event timing of the kernels, on the stream they are launched on
   bool profiling = false;
   bool prof_unit_only = false;  // profiling level 1: bracket the dominant (unit) kernel only
@@ -104,14 +254,18 @@ struct sann_batch {
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_unit_done) (void)hipEventDestroy(ev_unit_done);
     if (ev_all_done) (void)hipEventDestroy(ev_all_done);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
   }
+
+  template <class T> const T *staged(size_t off) const { return (const T *)((const char *)stage.p + off); }
+  template <class T> T *d_staged(size_t off) const { return (T *)((char *)d_stage.p + off); }
 
   BatchView view() const {
     BatchView b;
     b.hdr = hdr.as<QueryHdr>();
     b.scan_row = scan_row.as<int32_t>();
     b.scan_w = scan_w.as<double>();
-    b.scan_q = scan_q.as<int32_t>();
+    b.q_stat = (device_prep && use_fast) ? q_stat.as<uint4>() : nullptr;
     b.desc = desc.as<uint32_t>();
     b.unit_T = unit_T.as<int32_t>();
     for (int j = 0; j < 4; j++) { b.cut[j] = cut_ptr[j]; b.cut_M[j] = cut_M[j]; }
@@ -307,222 +461,172 @@ int sann_index_destroy(sann_index_t *ix) {
   return SANN_OK;
 }
 
+}  // extern "C"
+
 // ---------------------------------------------------------------------------------------------
 // batch
 // ---------------------------------------------------------------------------------------------
-int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t nq, const int64_t *emb_offsets,
-                      const int32_t *emb_cluster_ids, const double *emb_scores, const int64_t *source_tweet_ids,
-                      const uint8_t *has_source_tweet, const sann_config_t *configs, int32_t n_configs,
-                      const int64_t *scan_offsets, const int32_t *scan_cluster_ids, sann_batch_t **out) {
-  if (!out) return fail(SANN_EINVAL, "out is NULL");
-  *out = nullptr;
-  if (!ix) return fail(SANN_EINVAL, "index is NULL");
+namespace {
+
+inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// (Re)prepare `b` for nq new queries, reusing its device buffers, and enqueue on `st` whatever the preparation needs on
+// the device (one packed H2D copy + prep_kernel on the device path).  Asynchronous on the device path.
+int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const int64_t *emb_offsets,
+                const int32_t *emb_cluster_ids, const double *emb_scores, const int64_t *source_tweet_ids,
+                const uint8_t *has_source_tweet, const sann_config_t *configs, int32_t n_configs,
+                const int64_t *scan_offsets, const int32_t *scan_cluster_ids) {
+  sann_index *ix = b->ix;
+  const int variant = b->variant;
   if (nq < 0) return fail(SANN_EINVAL, "nq < 0");
-  if (variant < 0 || variant > 3) return fail(SANN_EINVAL, "unknown variant");
   if (nq > 0 && (!emb_offsets || !configs)) return fail(SANN_EINVAL, "emb_offsets/configs are NULL");
   if (n_configs != 1 && n_configs != nq) return fail(SANN_EINVAL, "n_configs must be 1 or nq");
   if ((scan_offsets == nullptr) != (scan_cluster_ids == nullptr) && nq > 0 && scan_offsets &&
       scan_offsets[nq] != scan_offsets[0])
     return fail(SANN_EINVAL, "scan_offsets and scan_cluster_ids must be given together");
   if ((int64_t)nq * ix->P > (int64_t)INT32_MAX / 2) return fail(SANN_ELIMIT, "nq * n_partitions too large");
+  const bool has_scan = scan_offsets != nullptr && scan_cluster_ids != nullptr;
+  const bool has_sources = has_source_tweet != nullptr && source_tweet_ids != nullptr;
 
-  sann_batch *b = new (std::nothrow) sann_batch();
-  if (!b) return fail(SANN_ENOMEM, "out of host memory");
-  struct Guard { sann_batch *b; ~Guard() { delete b; } } guard{b};
-  b->ix = ix;
-  b->nq = nq;
-  b->variant = variant;
-  b->n_units = nq * ix->P;
-  b->h_hdr.resize((size_t)nq);
-  b->h_k.resize((size_t)nq);
-
-  struct IdScore { int32_t id; double score; };
-  std::vector<IdScore> emb, by_id;
-  std::vector<int32_t> keys;
+  // ---- O(nq) pass over the arguments: validation, the scan regions' upper bounds, k, M ----------------------------
   int kmax = 1;
-  int64_t postings_scanned = 0, alg_bytes = 0;
-  std::vector<uint64_t> unit_bound((size_t)b->n_units, 0);
-  std::vector<double> unit_est((size_t)b->n_units, 0.0);  // expected postings with rank < M
-  std::vector<double> unit_var((size_t)b->n_units, 0.0);  // and the variance of that count
-
-  int max_n_scan = 0;
-  for (int32_t q = 0; q < nq; q++) {
-    const sann_config_t &cfg = configs[n_configs == 1 ? 0 : q];
-    int64_t eb = emb_offsets[q], ee = emb_offsets[q + 1];
-    if (ee < eb) return fail(SANN_EINVAL, "emb_offsets must be non-decreasing");
-    if (ee > eb && (!emb_cluster_ids || !emb_scores)) return fail(SANN_EINVAL, "embedding arrays are NULL");
-    // SimClustersEmbedding constructor: drop score <= 0, order by (score desc, cluster id asc)
-    emb.clear();
-    for (int64_t i = eb; i < ee; i++)
-      if (emb_scores[i] > 0.0) emb.push_back({emb_cluster_ids[i], emb_scores[i]});
-    std::sort(emb.begin(), emb.end(), [](const IdScore &x, const IdScore &y) {
-      int c = java_double_compare(y.score, x.score);
-      if (c) return c < 0;
-      return x.id < y.id;
-    });
-    by_id = emb;
-    std::stable_sort(by_id.begin(), by_id.end(), [](const IdScore &x, const IdScore &y) { return x.id < y.id; });
-    // CosineSimilarityUtil.sumOfSquaresArray over sortedScores (left fold)
-    double sumsq = 0.0;
-    for (const IdScore &x : by_id) sumsq = sumsq + x.score * x.score;
-
-    QueryHdr &h = b->h_hdr[(size_t)q];
-    h.l2norm = std::sqrt(sumsq);
-    h.lognorm = strict_log(sumsq + 1);
-    h.min_score = cfg.min_score;
+  int64_t max_emb = 0, total_ub = 0;
+  int max_ub = 0;
+  double apriori_mean = 0.0;  // largest expected unit size over the queries (see the geometry note below)
+  for (int32_t i = 0; i < n_configs; i++) {
+    const sann_config_t &cfg = configs[i];
     if (variant == SANN_VARIANT_LEGACY) {
-      // SimClustersANNCandidateSource.scala:160-180: the "log" form divides by l2norm, nothing is
-      // filtered by minScore, and there is no cap below maxNumResults
       if (cfg.ann_algorithm != SANN_ALG_DOT_PRODUCT && cfg.ann_algorithm != SANN_ALG_COSINE &&
           cfg.ann_algorithm != SANN_ALG_LOG_COSINE)
         return fail(SANN_EINVAL, "legacy variant: ann_algorithm must be dot product, cosine or log cosine");
       if (cfg.max_num_results > 1000) return fail(SANN_ELIMIT, "legacy variant: max_num_results above 1000");
-      h.lognorm = h.l2norm;
-      h.min_score = -std::numeric_limits<double>::infinity();
     }
-    h.M = cfg.max_top_tweets_per_cluster < 0 ? 0 : cfg.max_top_tweets_per_cluster;
     int k = cfg.max_num_results < 1000 ? cfg.max_num_results : 1000;
-    h.k = k < 0 ? 0 : k;
-    b->h_k[(size_t)q] = h.k;
-    kmax = std::max(kmax, h.k);
-    h.alg = cfg.ann_algorithm;
-    // age window (ApproximateCosineSimilarity.scala:65-72)
-    h.earliest = (cfg.max_tweet_candidate_age_hours >= 175200 && variant != SANN_VARIANT_LEGACY)
-                     ? 0
-                     : snowflake_first_id_for(now_ms - (int64_t)cfg.max_tweet_candidate_age_hours * 3600000ll);
-    h.latest = snowflake_first_id_for(now_ms - (int64_t)cfg.min_tweet_candidate_age_hours * 3600000ll);
-    // source-tweet exclusion (:90 ; Optimized :56,:67 ; Experimental :59,:70)
-    bool has_src = has_source_tweet && has_source_tweet[q] && source_tweet_ids;
-    if (variant == SANN_VARIANT_ORIGINAL || variant == SANN_VARIANT_LEGACY) {
-      h.excl_enabled = has_src ? 1 : 0;
-      h.src_excl = has_src ? source_tweet_ids[q] : 0;
-    } else {
-      h.excl_enabled = 1;
-      h.src_excl = has_src ? source_tweet_ids[q] : 0;
-    }
-
-    // keys of clusterTweetsMap in accumulation order
-    keys.clear();
-    if (scan_offsets) {
-      for (int64_t i = scan_offsets[q]; i < scan_offsets[q + 1]; i++) keys.push_back(scan_cluster_ids[i]);
-    } else {
-      // truncate(maxScanClusters).getClusterIds().toSet -> ascending cluster id
-      int64_t n = cfg.max_scan_clusters < 0 ? 0 : std::min<int64_t>((int64_t)emb.size(), cfg.max_scan_clusters);
-      for (int64_t i = 0; i < n; i++) keys.push_back(emb[(size_t)i].id);
-      std::sort(keys.begin(), keys.end());
-    }
-    h.scan_begin = (int32_t)b->h_scan_row.size();
-    for (int32_t cluster : keys) {
-      auto it = std::lower_bound(by_id.begin(), by_id.end(), cluster,
-                                 [](const IdScore &x, int32_t c) { return x.id < c; });
-      bool contained = it != by_id.end() && it->id == cluster;
-      if (!contained && variant != SANN_VARIANT_EXPERIMENTAL) continue;  // `if sourceEmbedding.contains(clusterId)`
-      double w = contained ? it->score : 0.0;                             // getOrElse(clusterId)
-      int row = ix->row_of(cluster);
-      if (row < 0) continue;  // None in clusterTweetsMap
-      b->h_scan_row.push_back(row);
-      b->h_scan_w.push_back(w);
-      b->h_scan_q.push_back(q);
-      uint64_t bound_sum = 0;
-      const uint64_t whole = ix->h_sub_offsets[(size_t)(row + 1) * ix->P] - ix->h_sub_offsets[(size_t)row * ix->P];
-      // share of the list with rank < M, as if this shard held 1/n_shards of every list
-      const double frac = whole == 0 ? 0.0 : std::min(1.0, (double)h.M / ((double)whole * ix->n_shards));
-      for (int p = 0; p < ix->P; p++) {
-        uint64_t len = ix->h_sub_offsets[(size_t)row * ix->P + p + 1] - ix->h_sub_offsets[(size_t)row * ix->P + p];
-        uint64_t lim = std::min<uint64_t>(len, (uint64_t)h.M);
-        unit_bound[(size_t)q * ix->P + p] += lim;
-        unit_est[(size_t)q * ix->P + p] += (double)len * frac;
-        unit_var[(size_t)q * ix->P + p] += (double)len * frac * (1.0 - frac);  // each posting has rank < M with prob. frac
-        bound_sum += lim;
-      }
-      // exact when this shard holds whole lists: min(len_c, M) postings have rank < M
-      postings_scanned += (int64_t)(ix->n_shards == 1 ? std::min<uint64_t>(whole, (uint64_t)h.M) : bound_sum);
-    }
-    h.n_scan = (int32_t)b->h_scan_row.size() - h.scan_begin;
-    max_n_scan = std::max(max_n_scan, (int)h.n_scan);
-    alg_bytes += (int64_t)h.n_scan * 12;
+    kmax = std::max(kmax, k);
   }
-  // postings_scanned = sum_c min(len_c, M) (SURVEY 8d's P_q) when the shard holds whole lists;
-  // with tweet-hash shards it is the per-sub-list upper bound sum_p min(len_p, M).
-  b->stats.postings_scanned = postings_scanned;
-  b->stats.algorithmic_bytes = alg_bytes + postings_scanned * 16;
-  b->stats.n_units = b->n_units;
+  HIP_TRY(hipSetDevice(ix->device));
+  // staging layout (one pinned block, one H2D copy)
+  sann_batch::StageLayout L;
+  L.has_scan = has_scan;
+  L.has_sources = has_sources;
+  L.n_configs = n_configs;
+  const int64_t e0 = nq ? emb_offsets[0] : 0, e1 = nq ? emb_offsets[nq] : 0;
+  const int64_t s0 = (nq && has_scan) ? scan_offsets[0] : 0, s1 = (nq && has_scan) ? scan_offsets[nq] : 0;
+  if (e1 < e0 || s1 < s0) return fail(SANN_EINVAL, "offsets must be non-decreasing");
+  if (e1 > e0 && (!emb_cluster_ids || !emb_scores)) return fail(SANN_EINVAL, "embedding arrays are NULL");
+  {
+    size_t o = 0;
+    L.emb_offsets = o; o = align16(o + ((size_t)nq + 1) * 8);
+    L.src_ids = o; o = align16(o + (has_sources ? (size_t)nq * 8 : 0));
+    L.scan_offsets = o; o = align16(o + (has_scan ? ((size_t)nq + 1) * 8 : 0));
+    L.emb_scores = o; o = align16(o + (size_t)(e1 - e0) * 8);
+    L.emb_cids = o; o = align16(o + (size_t)(e1 - e0) * 4);
+    L.scan_cids = o; o = align16(o + (size_t)(s1 - s0) * 4);
+    L.configs = o; o = align16(o + (size_t)n_configs * sizeof(sann_config_t));
+    L.scan_begin = o; o = align16(o + (size_t)nq * 4);
+    L.has_src = o; o = align16(o + (has_sources ? (size_t)nq : 0));
+    L.bytes = o;
+  }
+  HIP_TRY(b->stage.reserve(std::max<size_t>(L.bytes, 16)));
+  char *S = (char *)b->stage.p;
+  int64_t *st_eo = (int64_t *)(S + L.emb_offsets);
+  int64_t *st_so = (int64_t *)(S + L.scan_offsets);
+  int32_t *st_sb = (int32_t *)(S + L.scan_begin);
+  for (int32_t q = 0; q < nq; q++) {
+    const sann_config_t &cfg = configs[n_configs == 1 ? 0 : q];
+    const int64_t n_raw = emb_offsets[q + 1] - emb_offsets[q];
+    if (n_raw < 0) return fail(SANN_EINVAL, "emb_offsets must be non-decreasing");
+    max_emb = std::max(max_emb, n_raw);
+    int64_t ub;
+    if (has_scan) {
+      ub = scan_offsets[q + 1] - scan_offsets[q];
+      if (ub < 0) return fail(SANN_EINVAL, "scan_offsets must be non-decreasing");
+    } else {
+      ub = cfg.max_scan_clusters < 0 ? 0 : std::min<int64_t>(n_raw, cfg.max_scan_clusters);
+    }
+    if (total_ub + ub > (int64_t)INT32_MAX / 4) return fail(SANN_ELIMIT, "too many scanned clusters in one batch");
+    st_eo[q] = emb_offsets[q] - e0;
+    if (has_scan) st_so[q] = scan_offsets[q] - s0;
+    st_sb[q] = (int32_t)total_ub;
+    total_ub += ub;
+    max_ub = (int)std::max<int64_t>(max_ub, std::min<int64_t>(ub, INT32_MAX));
+    const double M = (double)std::max(cfg.max_top_tweets_per_cluster, 0);
+    apriori_mean = std::max(apriori_mean, (double)ub * std::min(M, (double)ix->max_list_len));
+  }
+  if (nq) {
+    st_eo[nq] = e1 - e0;
+    if (has_scan) st_so[nq] = s1 - s0;
+  }
+  apriori_mean /= (double)ix->P * (double)ix->n_shards;
 
+  b->nq = nq;
+  b->now_ms = now_ms;
+  b->n_units = nq * ix->P;
+  b->lay = L;
   b->stride = kmax;
   b->cap2 = kmax;
+  b->cap = FAST_SCAP;  // a fast unit emits at most its survivor list
+  b->ran = false;
+  b->unit_done_recorded = false;
+  b->stats = sann_batch_stats_t{};
+  b->stats.n_units = b->n_units;
+  b->unit_bound.clear();
   {
-    uint32_t mb = 0;
-    b->unit_bound.resize((size_t)b->n_units);
-    for (int u = 0; u < b->n_units; u++) {
-      b->unit_bound[(size_t)u] = (uint32_t)std::min<uint64_t>(unit_bound[(size_t)u], 0x7fffffffu);
-      mb = std::max(mb, b->unit_bound[(size_t)u]);
-    }
-  }
-  // ---- fast-path geometry -----------------------------------------------------------------
-  // postings per unit held in registers: the smallest geometry under which fewer than 0.1 units of the batch are
-  // expected to overflow (a unit's count of postings with rank < M is its sub-lists' lengths thinned with
-  // probability frac: mean and variance are known, normal tail); a unit that does overflow goes to the general path
-  // on its own -- about 0.15 ms for the batch that has one, against 30 us per batch that the next smaller geometry
-  // saves.  (25 % headroom over the largest mean, the first rule, put the benchmark's units -- mean <= 1340,
-  // sigma 28 -- into the 2048-posting geometry; the 1536 one is 3 % faster: two register slots fewer, no spill.)
-  {
-    static const int kCaps[] = {256, 512, 768, 1024, 1536, 2048, 3072, 4096};  // workgroup size x postings per thread
-    int ucap = 4096;
-    for (int c : kCaps) {
-      double expected_overflows = 0.0;
-      for (size_t u = 0; u < unit_est.size() && expected_overflows < 0.1; u++) {
-        const double room = (double)c - 16.0 - unit_est[u];
-        if (room <= 0.0) { expected_overflows += 1.0; continue; }
-        if (unit_var[u] > 0.0) expected_overflows += 0.5 * std::erfc(room / std::sqrt(2.0 * unit_var[u]));
-      }
-      if (expected_overflows < 0.1) { ucap = c; break; }
-    }
-    if (const char *ov = getenv("SANN_UNIT_CAP")) ucap = atoi(ov);  // tuning / test override
-    b->fast.unit_capacity = ucap;
-    b->fast.k_local = 0;
-    b->fast.max_n_scan = max_n_scan;
-    b->cap = FAST_SCAP;  // a fast unit emits at most its survivor list
     const char *force = getenv("SANN_FORCE_GENERAL");
     b->use_fast = !(force && force[0] == '1');
+    const char *hp = getenv("SANN_HOST_PREP");
+    b->device_prep = b->use_fast && max_emb <= PREP_MAX && !(hp && hp[0] == '1');
   }
 
-  HIP_TRY(hipSetDevice(ix->device));
-  size_t nu = (size_t)std::max(b->n_units, 1), nqz = (size_t)std::max(nq, 1);
-  HIP_TRY(b->hdr.alloc(nqz * sizeof(QueryHdr)));
-  HIP_TRY(b->scan_row.alloc(std::max<size_t>(b->h_scan_row.size(), 1) * 4));
-  HIP_TRY(b->scan_w.alloc(std::max<size_t>(b->h_scan_w.size(), 1) * 8));
-  HIP_TRY(b->scan_q.alloc(std::max<size_t>(b->h_scan_q.size(), 1) * 4));
-  HIP_TRY(b->desc.alloc(std::max<size_t>(b->h_scan_row.size(), 1) * (size_t)ix->P * 8));
-  HIP_TRY(b->unit_T.alloc(nu * 4));
-  HIP_TRY(b->d_k.alloc(nqz * 4));
-  HIP_TRY(b->cand_key.alloc(nu * (size_t)b->cap * 8));
-  HIP_TRY(b->cand_id.alloc(nu * (size_t)b->cap * 8));
-  HIP_TRY(b->cand_cnt.alloc(nu * 4));
-  HIP_TRY(b->unit_unique.alloc(nu * 4));
-  HIP_TRY(b->unit_flags.alloc(nu * 4));
-  HIP_TRY(b->unit_fb.alloc(nu * 4));
-  HIP_TRY(b->unit_thr.alloc(nu * 16));
-  HIP_TRY(b->status.alloc((nqz + 2) * 4));
-  HIP_TRY(b->overflow_units.alloc(nu * 4));
-  HIP_TRY(b->out_ids.alloc(nqz * (size_t)b->stride * 8));
-  HIP_TRY(b->out_scores.alloc(nqz * (size_t)b->stride * 8));
-  HIP_TRY(b->out_counts.alloc(nqz * 4));
-  HIP_TRY(b->out_map_sizes.alloc(nqz * 4));
-  HIP_TRY(hipHostMalloc((void **)&b->h_status, (nqz + 2) * 4, hipHostMallocDefault));
-  if (nq > 0) {
-    HIP_TRY(hipMemcpy(b->hdr.p, b->h_hdr.data(), (size_t)nq * sizeof(QueryHdr), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->d_k.p, b->h_k.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
+  // the packed inputs are kept either way: the device path uploads them, the slow tail of the host path never needs
+  // them, and the slow tail of the device path re-prepares the flagged queries from them
+  if (nq) {
+    memcpy(S + L.emb_scores, emb_scores + e0, (size_t)(e1 - e0) * 8);
+    memcpy(S + L.emb_cids, emb_cluster_ids + e0, (size_t)(e1 - e0) * 4);
+    if (has_scan) memcpy(S + L.scan_cids, scan_cluster_ids + s0, (size_t)(s1 - s0) * 4);
+    memcpy(S + L.configs, configs, (size_t)n_configs * sizeof(sann_config_t));
+    if (has_sources) {
+      memcpy(S + L.src_ids, source_tweet_ids, (size_t)nq * 8);
+      memcpy(S + L.has_src, has_source_tweet, (size_t)nq);
+    }
   }
-  if (!b->h_scan_row.empty()) {
-    HIP_TRY(hipMemcpy(b->scan_row.p, b->h_scan_row.data(), b->h_scan_row.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->scan_w.p, b->h_scan_w.data(), b->h_scan_w.size() * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->scan_q.p, b->h_scan_q.data(), b->h_scan_q.size() * 4, hipMemcpyHostToDevice));
-  }
-  // cut tables for the batch's (up to 4) distinct values of M, built once per index and M
-  if (b->use_fast) {
+
+  // ---- device buffers (kept between resets; they only grow) -------------------------------------------------------
+  const size_t nu = (size_t)std::max(b->n_units, 1), nqz = (size_t)std::max(nq, 1);
+  const size_t scan_cap = (size_t)std::max<int64_t>(total_ub, 1);
+  HIP_TRY(b->hdr.reserve(nqz * sizeof(QueryHdr)));
+  HIP_TRY(b->scan_row.reserve(scan_cap * 4));
+  HIP_TRY(b->scan_w.reserve(scan_cap * 8));
+  HIP_TRY(b->desc.reserve(scan_cap * (size_t)ix->P * 8));
+  HIP_TRY(b->unit_T.reserve(nu * 4));
+  HIP_TRY(b->d_k.reserve(nqz * 4));
+  HIP_TRY(b->q_stat.reserve(nqz * 16));
+  HIP_TRY(b->cand_key.reserve(nu * (size_t)b->cap * 8));
+  HIP_TRY(b->cand_id.reserve(nu * (size_t)b->cap * 8));
+  HIP_TRY(b->cand_cnt.reserve(nu * 4));
+  HIP_TRY(b->unit_unique.reserve(nu * 4));
+  HIP_TRY(b->unit_flags.reserve(nu * 4));
+  HIP_TRY(b->unit_fb.reserve(nu * 4));
+  HIP_TRY(b->unit_thr.reserve(nu * 16));
+  HIP_TRY(b->status.reserve((nqz + 2) * 4));
+  HIP_TRY(b->overflow_units.reserve(nu * 4));
+  HIP_TRY(b->out_ids.reserve(nqz * (size_t)b->stride * 8));
+  HIP_TRY(b->out_scores.reserve(nqz * (size_t)b->stride * 8));
+  HIP_TRY(b->out_counts.reserve(nqz * 4));
+  HIP_TRY(b->out_map_sizes.reserve(nqz * 4));
+  HIP_TRY(b->h_qstat.reserve(nqz * 16));
+  if (!b->h_status) HIP_TRY(hipHostMalloc((void **)&b->h_status, 2 * 4, hipHostMallocDefault));
+  b->h_status[0] = b->h_status[1] = 0;
+  // the general path's workspace is sized per batch (tables depend on the units' bounds)
+  b->g_cap_units = 0;
+  b->g_cap_entries = 0;
+
+  // ---- cut tables for the batch's (up to 4) distinct values of M, built once per index and M ------------------------
+  for (int j = 0; j < 4; j++) { b->cut_M[j] = -1; b->cut_ptr[j] = nullptr; }
+  if (b->use_fast && nq > 0) {
     int n_m = 0;
-    for (int32_t q = 0; q < nq && n_m < 4; q++) {
-      const int32_t M = b->h_hdr[(size_t)q].M;
+    for (int32_t i = 0; i < n_configs && n_m < 4; i++) {
+      const int32_t M = std::max(configs[i].max_top_tweets_per_cluster, 0);
       bool seen = false;
       for (int j = 0; j < n_m; j++) seen = seen || b->cut_M[j] == M;
       if (seen) continue;
@@ -534,8 +638,8 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
         if (!tab && ix->cut_cache.size() < 8) {
           std::unique_ptr<DevBuf> buf(new DevBuf());
           HIP_TRY(buf->alloc(std::max<size_t>((size_t)ix->cluster_ids.size() * ix->P, 1) * 4));
-          HIP_TRY(launch_cut(ix->view(), M, buf->as<uint32_t>(), nullptr));
-          HIP_TRY(hipStreamSynchronize(nullptr));
+          HIP_TRY(launch_cut(ix->view(), M, buf->as<uint32_t>(), st));
+          HIP_TRY(hipStreamSynchronize(st));
           tab = buf->as<uint32_t>();
           ix->cut_cache.emplace_back(M, std::move(buf));
         }
@@ -547,14 +651,197 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
       }
     }
   }
-  guard.b = nullptr;
+  b->fast.k_local = 0;
+  b->fast.max_n_scan = max_ub;
+
+  if (b->device_prep) {
+    // ---- device path: upload the packed inputs, prepare on the GPU ------------------------------------------------
+    // Geometry (postings a unit holds in registers).  The host no longer sees which clusters a query scans, so the
+    // choice is made from what it does know: a query scans at most ub clusters and at most min(M, longest list)
+    // postings of each, and a posting falls into this (shard, partition) with probability 1 / (n_shards * P): mean
+    // <= ub * min(M, max_len) / (n_shards * P), variance <= mean; five sigma of headroom keeps the expected number of
+    // overflowing units of a 32k-unit batch below 0.01.  That bound is loose for queries over short lists, so the
+    // index also remembers the largest unit recent batches really had (q_stat, read back with every batch) and the
+    // smaller of the two geometries is used; a unit that does overflow is re-run exactly on the general path.
+    int ucap = geometry_for(apriori_mean + 5.0 * std::sqrt(apriori_mean));
+    const int hint = ix->unit_size_hint.load(std::memory_order_relaxed);
+    if (hint > 0) ucap = std::min(ucap, geometry_for((double)hint + 2.0 * std::sqrt((double)hint)));
+    if (const char *ov = getenv("SANN_UNIT_CAP")) ucap = atoi(ov);  // tuning / test override
+    b->fast.unit_capacity = ucap;
+    HIP_TRY(ix->ensure_device_cluster_ids());
+    if (nq > 0) {
+      HIP_TRY(b->d_stage.reserve(L.bytes));
+      HIP_TRY(hipMemcpyAsync(b->d_stage.p, b->stage.p, L.bytes, hipMemcpyHostToDevice, st));
+      PrepView pv;
+      pv.emb_offsets = b->d_staged<int64_t>(L.emb_offsets);
+      pv.emb_cluster_ids = b->d_staged<int32_t>(L.emb_cids);
+      pv.emb_scores = b->d_staged<double>(L.emb_scores);
+      pv.source_tweet_ids = has_sources ? b->d_staged<int64_t>(L.src_ids) : nullptr;
+      pv.has_source_tweet = has_sources ? b->d_staged<uint8_t>(L.has_src) : nullptr;
+      pv.configs = b->d_staged<sann_config_t>(L.configs);
+      pv.scan_offsets = has_scan ? b->d_staged<int64_t>(L.scan_offsets) : nullptr;
+      pv.scan_cluster_ids = has_scan ? b->d_staged<int32_t>(L.scan_cids) : nullptr;
+      pv.scan_begin = b->d_staged<int32_t>(L.scan_begin);
+      pv.cluster_ids = ix->d_cluster_ids.as<int32_t>();
+      pv.hdr = b->hdr.as<QueryHdr>();
+      pv.scan_row = b->scan_row.as<int32_t>();
+      pv.scan_w = b->scan_w.as<double>();
+      pv.d_k = b->d_k.as<int32_t>();
+      pv.now_ms = now_ms;
+      pv.n_rows = (int32_t)ix->cluster_ids.size();
+      pv.n_configs = n_configs;
+      pv.variant = variant;
+      pv.nq = nq;
+      HIP_TRY(launch_prep(pv, st));
+    }
+    return SANN_OK;
+  }
+
+  // ---- host path ------------------------------------------------------------------------------------------------
+  b->h_hdr.resize((size_t)nq);
+  b->h_k.resize((size_t)nq);
+  b->h_scan_row.clear();
+  b->h_scan_w.clear();
+  std::vector<IdScore> emb, by_id;
+  std::vector<int32_t> keys;
+  HostQuery hq;
+  int64_t postings_scanned = 0, alg_bytes = 0;
+  std::vector<uint64_t> unit_bound((size_t)b->n_units, 0);
+  std::vector<double> unit_est((size_t)b->n_units, 0.0), unit_var((size_t)b->n_units, 0.0);
+  int max_n_scan = 0;
+  for (int32_t q = 0; q < nq; q++) {
+    const sann_config_t &cfg = configs[n_configs == 1 ? 0 : q];
+    const bool has_src = has_sources && has_source_tweet[q];
+    int rc = prepare_query_host(ix, variant, now_ms, cfg, emb_cluster_ids + emb_offsets[q], emb_scores + emb_offsets[q],
+                                emb_offsets[q + 1] - emb_offsets[q], has_src, has_src ? source_tweet_ids[q] : 0,
+                                has_scan ? scan_cluster_ids + scan_offsets[q] : nullptr,
+                                has_scan ? scan_offsets[q + 1] - scan_offsets[q] : -1, hq, emb, by_id, keys);
+    if (rc != SANN_OK) return rc;
+    hq.h.scan_begin = (int32_t)b->h_scan_row.size();
+    b->h_hdr[(size_t)q] = hq.h;
+    b->h_k[(size_t)q] = hq.h.k;
+    b->h_scan_row.insert(b->h_scan_row.end(), hq.rows.begin(), hq.rows.end());
+    b->h_scan_w.insert(b->h_scan_w.end(), hq.w.begin(), hq.w.end());
+    for (int p = 0; p < ix->P; p++) {
+      unit_bound[(size_t)q * ix->P + p] = hq.unit_bound[(size_t)p];
+      unit_est[(size_t)q * ix->P + p] = hq.unit_est[(size_t)p];
+      unit_var[(size_t)q * ix->P + p] = hq.unit_var[(size_t)p];
+    }
+    postings_scanned += hq.postings_scanned;
+    max_n_scan = std::max(max_n_scan, (int)hq.h.n_scan);
+    alg_bytes += (int64_t)hq.h.n_scan * 12;
+  }
+  // postings_scanned = sum_c min(len_c, M) (SURVEY 8d's P_q) when the shard holds whole lists;
+  // with tweet-hash shards it is the per-sub-list upper bound sum_p min(len_p, M).
+  b->stats.postings_scanned = postings_scanned;
+  b->stats.algorithmic_bytes = alg_bytes + postings_scanned * 16;
+  b->unit_bound.resize((size_t)b->n_units);
+  for (int u = 0; u < b->n_units; u++) b->unit_bound[(size_t)u] = (uint32_t)std::min<uint64_t>(unit_bound[(size_t)u], 0x7fffffffu);
+  // Geometry: the smallest one under which fewer than 0.1 units of the batch are expected to overflow (a unit's count
+  // of postings with rank < M is its sub-lists' lengths thinned with probability frac: mean and variance are known,
+  // normal tail); a unit that does overflow goes to the general path on its own.
+  {
+    static const int kCaps[] = {256, 512, 768, 1024, 1536, 2048, 3072, 4096};
+    int ucap = 4096;
+    for (int c : kCaps) {
+      double expected_overflows = 0.0;
+      for (size_t u = 0; u < unit_est.size() && expected_overflows < 0.1; u++) {
+        const double room = (double)c - 16.0 - unit_est[u];
+        if (room <= 0.0) { expected_overflows += 1.0; continue; }
+        if (unit_var[u] > 0.0) expected_overflows += 0.5 * std::erfc(room / std::sqrt(2.0 * unit_var[u]));
+      }
+      if (expected_overflows < 0.1) { ucap = c; break; }
+    }
+    if (const char *ov = getenv("SANN_UNIT_CAP")) ucap = atoi(ov);
+    b->fast.unit_capacity = ucap;
+    b->fast.max_n_scan = max_n_scan;
+  }
+  if (nq > 0) {
+    HIP_TRY(hipMemcpyAsync(b->hdr.p, b->h_hdr.data(), (size_t)nq * sizeof(QueryHdr), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_k.p, b->h_k.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
+  }
+  if (!b->h_scan_row.empty()) {
+    HIP_TRY(hipMemcpyAsync(b->scan_row.p, b->h_scan_row.data(), b->h_scan_row.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->scan_w.p, b->h_scan_w.data(), b->h_scan_w.size() * 8, hipMemcpyHostToDevice, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));  // pageable sources: done with them before returning
+  return SANN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t nq, const int64_t *emb_offsets,
+                      const int32_t *emb_cluster_ids, const double *emb_scores, const int64_t *source_tweet_ids,
+                      const uint8_t *has_source_tweet, const sann_config_t *configs, int32_t n_configs,
+                      const int64_t *scan_offsets, const int32_t *scan_cluster_ids, sann_batch_t **out) {
+  if (!out) return fail(SANN_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (!ix) return fail(SANN_EINVAL, "index is NULL");
+  if (variant < 0 || variant > 3) return fail(SANN_EINVAL, "unknown variant");
+  sann_batch *b = new (std::nothrow) sann_batch();
+  if (!b) return fail(SANN_ENOMEM, "out of host memory");
+  b->ix = ix;
+  b->variant = variant;
+  int rc = batch_reset(b, nullptr, now_ms, nq, emb_offsets, emb_cluster_ids, emb_scores, source_tweet_ids, has_source_tweet,
+                       configs, n_configs, scan_offsets, scan_cluster_ids);
+  // the batch may be run on any stream afterwards, non-blocking ones included: finish the preparation here
+  if (rc == SANN_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(SANN_EDEVICE, "preparing the batch failed");
+  if (rc != SANN_OK) {
+    std::string keep = g_err;
+    (void)hipSetDevice(ix->device);
+    delete b;
+    g_err = keep;
+    return rc;
+  }
   *out = b;
   return SANN_OK;
+}
+
+int sann_batch_reset(sann_batch_t *b, void *hip_stream, int64_t now_ms, int32_t nq, const int64_t *emb_offsets,
+                     const int32_t *emb_cluster_ids, const double *emb_scores, const int64_t *source_tweet_ids,
+                     const uint8_t *has_source_tweet, const sann_config_t *configs, int32_t n_configs,
+                     const int64_t *scan_offsets, const int32_t *scan_cluster_ids) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  return batch_reset(b, (hipStream_t)hip_stream, now_ms, nq, emb_offsets, emb_cluster_ids, emb_scores, source_tweet_ids,
+                     has_source_tweet, configs, n_configs, scan_offsets, scan_cluster_ids);
 }
 
 }  // extern "C"
 
 namespace {
+
+// Device-prepared batches: the host never saw which clusters the queries scan.  The slow tail needs, for the queries
+// it re-runs, an upper bound on every unit's postings (the general path's table sizes): prepare just those queries
+// on the host, from the packed copy of the caller's arrays.
+int ensure_unit_bounds(sann_batch *b, const std::vector<int32_t> &queries) {
+  if (!b->device_prep) return SANN_OK;
+  const int P = b->ix->P;
+  if (b->unit_bound.size() != (size_t)b->n_units) b->unit_bound.assign((size_t)b->n_units, 0u);
+  const auto &L = b->lay;
+  const int64_t *eo = b->staged<int64_t>(L.emb_offsets);
+  const int64_t *so = b->staged<int64_t>(L.scan_offsets);
+  const int32_t *ec = b->staged<int32_t>(L.emb_cids);
+  const double *es = b->staged<double>(L.emb_scores);
+  const int32_t *sc = b->staged<int32_t>(L.scan_cids);
+  const sann_config_t *cfgs = b->staged<sann_config_t>(L.configs);
+  const int64_t *src = b->staged<int64_t>(L.src_ids);
+  const uint8_t *has = b->staged<uint8_t>(L.has_src);
+  std::vector<IdScore> emb, by_id;
+  std::vector<int32_t> keys;
+  HostQuery hq;
+  for (int32_t q : queries) {
+    const bool has_src = L.has_sources && has[q];
+    int rc = prepare_query_host(b->ix, b->variant, b->now_ms, cfgs[L.n_configs == 1 ? 0 : q], ec + eo[q], es + eo[q],
+                                eo[q + 1] - eo[q], has_src, has_src ? src[q] : 0, L.has_scan ? sc + so[q] : nullptr,
+                                L.has_scan ? so[q + 1] - so[q] : -1, hq, emb, by_id, keys);
+    if (rc != SANN_OK) return rc;
+    for (int p = 0; p < P; p++)
+      b->unit_bound[(size_t)q * P + p] = (uint32_t)std::min<uint64_t>(hq.unit_bound[(size_t)p], 0x7fffffffu);
+  }
+  return SANN_OK;
+}
 
 // Run the general (global-memory table) kernel on `units` (empty = every unit of the batch) and
 // leave their candidate lists in the cand_*2 buffers.  Buffers grow on demand.
@@ -572,22 +859,14 @@ int run_general(sann_batch *b, const std::vector<int32_t> &units, hipStream_t st
     slots[(size_t)i] = S;
     run += (int64_t)S + 1;
   }
-  if (n > b->g_cap_units) {
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(b->g_units.alloc((size_t)n * 4));
-    HIP_TRY(b->g_off.alloc((size_t)n * 8));
-    HIP_TRY(b->g_slots.alloc((size_t)n * 4));
-    HIP_TRY(b->cand_key2.alloc((size_t)n * (size_t)b->cap2 * 8));
-    HIP_TRY(b->cand_id2.alloc((size_t)n * (size_t)b->cap2 * 8));
-    b->g_cap_units = n;
-  }
-  if (run > b->g_cap_entries) {
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(b->g_keys.alloc((size_t)run * 8));
-    HIP_TRY(b->g_dot.alloc((size_t)run * 8));
-    HIP_TRY(b->g_nsq.alloc((size_t)run * 8));
-    b->g_cap_entries = run;
-  }
+  HIP_TRY(b->g_units.reserve((size_t)n * 4));
+  HIP_TRY(b->g_off.reserve((size_t)n * 8));
+  HIP_TRY(b->g_slots.reserve((size_t)n * 4));
+  HIP_TRY(b->cand_key2.reserve((size_t)n * (size_t)b->cap2 * 8));
+  HIP_TRY(b->cand_id2.reserve((size_t)n * (size_t)b->cap2 * 8));
+  HIP_TRY(b->g_keys.reserve((size_t)run * 8));
+  HIP_TRY(b->g_dot.reserve((size_t)run * 8));
+  HIP_TRY(b->g_nsq.reserve((size_t)run * 8));
   // the tiny descriptor arrays are copied synchronously (pageable host memory)
   if (!all) HIP_TRY(hipMemcpy(b->g_units.p, units.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->g_off.p, off.data(), (size_t)n * 8, hipMemcpyHostToDevice));
@@ -620,13 +899,7 @@ static int batch_run(sann_batch_t *b, void *hip_stream, bool chained, sann_batch
     HIP_TRY(hipMemsetAsync(b->status.p, 0, ((size_t)b->nq + 2) * 4, st));
     HIP_TRY(hipMemsetAsync(b->unit_fb.p, 0xFF, (size_t)b->n_units * 4, st));
   }
-  if (!b->use_fast && b->g_cap_units < b->n_units) {
-    // all-general mode: size the workspace before the timed launches
-    std::vector<int32_t> none;
-    if (b->profiling) HIP_TRY(hipEventRecord(b->ev[0], st));
-    int rc = run_general(b, none, st);
-    if (rc != SANN_OK) return rc;
-  } else {
+  {
     if (b->profiling && !(b->prof_unit_only && b->use_fast)) HIP_TRY(hipEventRecord(b->ev[0], st));
     if (b->use_fast) {
       hipError_t e = launch_desc(b->ix->view(), b->view(), b->n_units, b->fast.max_n_scan, st);
@@ -656,6 +929,10 @@ static int batch_run(sann_batch_t *b, void *hip_stream, bool chained, sann_batch
   }
   if (chained) HIP_TRY(hipEventRecord(b->ev_all_done, st));
   HIP_TRY(hipMemcpyAsync(b->h_status, b->status.p, 2 * 4, hipMemcpyDeviceToHost, st));
+  if (b->device_prep && b->use_fast) {
+    HIP_TRY(hipMemcpyAsync(b->h_qstat.p, b->q_stat.p, (size_t)b->nq * 16, hipMemcpyDeviceToHost, st));
+    b->qstat_pending = true;
+  }
   b->ran = true;
   return SANN_OK;
 }
@@ -691,6 +968,27 @@ int sann_batch_finish(sann_batch_t *b, void *hip_stream) {
     b->timed_runs++;
     b->ev_pending = false;
   }
+  if (b->qstat_pending) {
+    // the batch's shape as the device found it: postings scanned, scanned clusters, largest unit
+    const uint32_t *qs = (const uint32_t *)b->h_qstat.p;
+    int64_t postings = 0, clusters = 0;
+    uint32_t t_max = 0;
+    for (int q = 0; q < b->nq; q++) {
+      t_max = std::max(t_max, qs[4 * q]);
+      postings += qs[4 * q + 1];
+      clusters += qs[4 * q + 2];
+    }
+    b->stats.postings_scanned = postings;
+    b->stats.algorithmic_bytes = clusters * 12 + postings * 16;
+    b->stats.max_unit_postings = (int32_t)t_max;
+    // geometry hint for the next batches on this index: the largest unit seen, forgotten at 2 % per batch
+    sann_index *ix = b->ix;
+    int cur = ix->unit_size_hint.load(std::memory_order_relaxed);
+    const int decayed = cur - cur / 50;
+    const int next = std::max<int>((int)t_max, std::max(decayed, 1));
+    ix->unit_size_hint.store(next, std::memory_order_relaxed);
+    b->qstat_pending = false;
+  }
   const int n_over = b->h_status[0], n_inexact = b->h_status[1];
   if (n_over == 0 && n_inexact == 0) return SANN_OK;
   if (!b->use_fast) return fail(SANN_EINTERNAL, "general path reported overflow/inexact units");
@@ -716,9 +1014,11 @@ int sann_batch_finish(sann_batch_t *b, void *hip_stream) {
   }
   std::sort(units.begin(), units.end());
   units.erase(std::unique(units.begin(), units.end()), units.end());
-  int rc = run_general(b, units, st);
+  int rc = ensure_unit_bounds(b, queries);
   if (rc != SANN_OK) return rc;
-  HIP_TRY(b->g_queries.alloc(queries.size() * 4));
+  rc = run_general(b, units, st);
+  if (rc != SANN_OK) return rc;
+  HIP_TRY(b->g_queries.reserve(queries.size() * 4));
   HIP_TRY(hipMemcpy(b->g_queries.p, queries.data(), queries.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemsetAsync(b->status.p, 0, 2 * 4, st));
   HIP_TRY(launch_merge(b->ix->view(), b->view(), b->g_queries.as<int32_t>(), (int)queries.size(), st));
@@ -731,23 +1031,34 @@ int sann_batch_finish(sann_batch_t *b, void *hip_stream) {
   return SANN_OK;
 }
 
-int sann_batch_results(sann_batch_t *b, int64_t *out_ids, double *out_scores, int32_t out_stride, int32_t *out_counts,
-                       int32_t *out_map_sizes) {
-  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+static int results_impl(sann_batch_t *b, hipStream_t st, int64_t *out_ids, double *out_scores, int32_t out_stride,
+                        int32_t *out_counts, int32_t *out_map_sizes) {
   if (b->nq == 0) return SANN_OK;
   if (out_stride < b->stride) return fail(SANN_EINVAL, "out_stride smaller than the batch's max k");
   if (b->bound_chunk_q > 0) return fail(SANN_EINVAL, "outputs are bound to caller-owned chunked buffers");
   HIP_TRY(hipSetDevice(b->ix->device));
   BatchView bv = b->view();
-  if (out_ids)
-    HIP_TRY(hipMemcpy2D(out_ids, (size_t)out_stride * 8, bv.out_ids, (size_t)b->stride * 8, (size_t)b->stride * 8,
-                        (size_t)b->nq, hipMemcpyDeviceToHost));
-  if (out_scores)
-    HIP_TRY(hipMemcpy2D(out_scores, (size_t)out_stride * 8, bv.out_scores, (size_t)b->stride * 8,
-                        (size_t)b->stride * 8, (size_t)b->nq, hipMemcpyDeviceToHost));
-  if (out_counts) HIP_TRY(hipMemcpy(out_counts, bv.out_counts, (size_t)b->nq * 4, hipMemcpyDeviceToHost));
-  if (out_map_sizes) HIP_TRY(hipMemcpy(out_map_sizes, bv.out_map_sizes, (size_t)b->nq * 4, hipMemcpyDeviceToHost));
+  // rows are contiguous when the caller's stride is the batch's: one copy per array (at PCIe speed into pinned
+  // memory, see sann_host_alloc; staged by the runtime into pageable memory)
+  const size_t row = (size_t)b->stride * 8;
+  if (out_ids) {
+    if (out_stride == b->stride) HIP_TRY(hipMemcpyAsync(out_ids, bv.out_ids, row * (size_t)b->nq, hipMemcpyDeviceToHost, st));
+    else HIP_TRY(hipMemcpy2DAsync(out_ids, (size_t)out_stride * 8, bv.out_ids, row, row, (size_t)b->nq, hipMemcpyDeviceToHost, st));
+  }
+  if (out_scores) {
+    if (out_stride == b->stride) HIP_TRY(hipMemcpyAsync(out_scores, bv.out_scores, row * (size_t)b->nq, hipMemcpyDeviceToHost, st));
+    else HIP_TRY(hipMemcpy2DAsync(out_scores, (size_t)out_stride * 8, bv.out_scores, row, row, (size_t)b->nq, hipMemcpyDeviceToHost, st));
+  }
+  if (out_counts) HIP_TRY(hipMemcpyAsync(out_counts, bv.out_counts, (size_t)b->nq * 4, hipMemcpyDeviceToHost, st));
+  if (out_map_sizes) HIP_TRY(hipMemcpyAsync(out_map_sizes, bv.out_map_sizes, (size_t)b->nq * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return SANN_OK;
+}
+
+int sann_batch_results(sann_batch_t *b, int64_t *out_ids, double *out_scores, int32_t out_stride, int32_t *out_counts,
+                       int32_t *out_map_sizes) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  return results_impl(b, b->own_stream, out_ids, out_scores, out_stride, out_counts, out_map_sizes);
 }
 
 int sann_batch_device_results(sann_batch_t *b, void **d_ids, void **d_scores, void **d_counts, void **d_map_sizes,
@@ -900,6 +1211,12 @@ int sann_device_synchronize(int32_t device) {
   return SANN_OK;
 }
 
+}  // extern "C"
+sann_index::~sann_index() {
+  for (sann_batch *b : pool) delete b;
+}
+extern "C" {
+
 int sann_batch_destroy(sann_batch_t *b) {
   if (!b) return SANN_OK;
   (void)hipSetDevice(b->ix->device);
@@ -907,23 +1224,71 @@ int sann_batch_destroy(sann_batch_t *b) {
   return SANN_OK;
 }
 
+// One call = (pooled batch) reset + run + finish + results: the shape a JNI stub binds.  Every concurrent caller works on
+// a batch object of its own, taken from the index's pool and given back afterwards, on that object's own non-blocking
+// stream: after the first few calls nothing is allocated, and callers on different threads overlap on the GPU.
 int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_ms, int32_t nq,
                               const int64_t *emb_offsets, const int32_t *emb_cluster_ids, const double *emb_scores,
                               const int64_t *source_tweet_ids, const uint8_t *has_source_tweet,
                               const sann_config_t *configs, int32_t n_configs, const int64_t *scan_offsets,
                               const int32_t *scan_cluster_ids, int64_t *out_ids, double *out_scores,
                               int32_t out_stride, int32_t *out_counts, int32_t *out_map_sizes) {
-  sann_batch_t *b = nullptr;
-  int rc = sann_batch_create(index, variant, now_ms, nq, emb_offsets, emb_cluster_ids, emb_scores, source_tweet_ids,
-                             has_source_tweet, configs, n_configs, scan_offsets, scan_cluster_ids, &b);
-  if (rc != SANN_OK) return rc;
-  rc = sann_batch_run(b, nullptr);
-  if (rc == SANN_OK) rc = sann_batch_finish(b, nullptr);
-  if (rc == SANN_OK) rc = sann_batch_results(b, out_ids, out_scores, out_stride, out_counts, out_map_sizes);
+  if (!index) return fail(SANN_EINVAL, "index is NULL");
+  if (variant < 0 || variant > 3) return fail(SANN_EINVAL, "unknown variant");
+  sann_batch *b = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(index->pool_mu);
+    if (!index->pool.empty()) {
+      b = index->pool.back();
+      index->pool.pop_back();
+    }
+  }
+  if (!b) {
+    HIP_TRY(hipSetDevice(index->device));
+    b = new (std::nothrow) sann_batch();
+    if (!b) return fail(SANN_ENOMEM, "out of host memory");
+    b->ix = index;
+    hipError_t e = hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete b;
+      return fail(SANN_EDEVICE, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e));
+    }
+  }
+  b->variant = variant;
+  hipStream_t st = b->own_stream;
+  int rc = batch_reset(b, st, now_ms, nq, emb_offsets, emb_cluster_ids, emb_scores, source_tweet_ids, has_source_tweet,
+                       configs, n_configs, scan_offsets, scan_cluster_ids);
+  if (rc == SANN_OK) rc = sann_batch_run(b, st);
+  if (rc == SANN_OK) rc = sann_batch_finish(b, st);
+  if (rc == SANN_OK) rc = results_impl(b, st, out_ids, out_scores, out_stride, out_counts, out_map_sizes);
   std::string keep = g_err;
-  sann_batch_destroy(b);
+  bool pooled = false;
+  if (rc == SANN_OK || rc == SANN_EINVAL || rc == SANN_ELIMIT) {  // a device error may have left the object in an unknown state
+    std::lock_guard<std::mutex> lk(index->pool_mu);
+    if (index->pool.size() < 16) {
+      index->pool.push_back(b);
+      pooled = true;
+    }
+  }
+  if (!pooled) {
+    (void)hipSetDevice(index->device);
+    (void)hipStreamSynchronize(st);
+    delete b;
+  }
   if (rc != SANN_OK) g_err = keep;
   return rc;
+}
+
+int sann_host_alloc(int64_t bytes, void **out) {
+  if (!out || bytes < 0) return fail(SANN_EINVAL, "bad arguments");
+  *out = nullptr;
+  if (bytes == 0) return SANN_OK;
+  HIP_TRY(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+  return SANN_OK;
+}
+int sann_host_free(void *p) {
+  if (p) HIP_TRY(hipHostFree(p));
+  return SANN_OK;
 }
 
 int sann_merge_shards(int32_t device, void *hip_stream, int32_t n_shards, int32_t nq, int32_t stride,

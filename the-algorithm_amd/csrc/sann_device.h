@@ -13,6 +13,7 @@
 // unit can aggregate, normalise and select on its own; partitions and shards are merged by an
 // exact top-k merge (the ComposedQueryable pattern, ann/.../common/ShardApi.scala:71-87).
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace sann {
@@ -58,7 +59,10 @@ struct BatchView {
   const QueryHdr *hdr;
   const int32_t *scan_row;
   const double *scan_w;
-  const int32_t *scan_q;    // [total_scan] query of every scan entry
+  // [nq] per query, written by the merge kernel when not NULL: x = largest unit_T, y = sum of unit_T (postings with
+  // rank < M scanned in this shard), z = scanned clusters, w = 0.  Lets the host learn a batch's shape without
+  // having prepared it (device-side preparation, sann_prep.hip).
+  uint4 *q_stat;
   uint32_t *desc;           // [total_scan*P*2] (sub-list start, exclusive prefix of the lengths), unit-major
   int32_t *unit_T;          // [n_units] postings with rank < M the unit scans
   const uint32_t *cut[4];   // cached cut tables ([n_rows*P], see sann_index::cut_cache) ...

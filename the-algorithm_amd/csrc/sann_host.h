@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -30,11 +31,24 @@ struct DevBuf {
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { if (p) (void)hipFree(p); }
+  size_t cap = 0;
   hipError_t alloc(size_t n) {
     if (p) { (void)hipFree(p); p = nullptr; }
     bytes = n;
+    cap = 0;
     if (n == 0) return hipSuccess;
-    return hipMalloc(&p, n);
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  // Make room for n bytes, keeping the allocation when it is large enough (contents are NOT kept when it grows):
+  // a batch object that is reset for every request allocates only while its requests are still growing.
+  hipError_t reserve(size_t n) {
+    if (n <= cap) { bytes = n; return hipSuccess; }
+    const size_t want = n + n / 4;
+    hipError_t e = alloc(want);
+    if (e == hipSuccess) bytes = n;
+    return e;
   }
   template <class T> T *as() const { return (T *)p; }
 };
@@ -54,6 +68,27 @@ struct sann_index {
   // (one binary search per sub-list, on the device) and reused by every batch.
   std::mutex cut_mu;
   std::vector<std::pair<int32_t, std::unique_ptr<sann_host::DevBuf>>> cut_cache;
+
+  // device copy of cluster_ids for the query-preparation kernel (made on first use)
+  sann_host::DevBuf d_cluster_ids;
+  std::once_flag d_cluster_ids_once;
+  hipError_t d_cluster_ids_err = hipSuccess;
+  hipError_t ensure_device_cluster_ids() {
+    std::call_once(d_cluster_ids_once, [this] {
+      hipError_t e = d_cluster_ids.alloc(std::max<size_t>(cluster_ids.size(), 1) * 4);
+      if (e == hipSuccess && !cluster_ids.empty())
+        e = hipMemcpy(d_cluster_ids.p, cluster_ids.data(), cluster_ids.size() * 4, hipMemcpyHostToDevice);
+      d_cluster_ids_err = e;
+    });
+    return d_cluster_ids_err;
+  }
+  // largest number of postings a (query, partition) unit of recent batches scanned (decays slowly; 0 = unknown):
+  // the device-prepared batches' geometry hint (sann_api.hip, batch_reset)
+  std::atomic<int> unit_size_hint{0};
+  // batch objects kept for sann_get_tweet_candidates (one per concurrent caller), reset per call
+  std::mutex pool_mu;
+  std::vector<struct sann_batch *> pool;
+  ~sann_index();
 
   sann::IndexView view() const {
     sann::IndexView v;

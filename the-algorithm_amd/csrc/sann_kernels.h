@@ -4,6 +4,8 @@
 
 #include "sann_device.h"
 
+struct sann_config;
+
 namespace sann {
 
 hipError_t launch_unit_general(const IndexView &ix, const BatchView &b, const GeneralWs &ws, int n_units,
@@ -17,6 +19,28 @@ hipError_t launch_merge_shards(int n_shards, int nq, int stride, int64_t pitch, 
 
 hipError_t launch_debug_normalise(int alg, int n, const double *dot, const double *nsq, double l2norm, double lognorm,
                                   double *out, hipStream_t stream);
+
+// Query preparation on the device (sann_prep.hip): raw embeddings + configs in, QueryHdr + scan rows / weights out.
+constexpr int PREP_MAX = 1024;  // embedding entries a query may have on the device path (longer ones: host path)
+struct PrepView {
+  const int64_t *emb_offsets;       // [nq+1]
+  const int32_t *emb_cluster_ids;
+  const double *emb_scores;
+  const int64_t *source_tweet_ids;  // [nq] or NULL
+  const uint8_t *has_source_tweet;  // [nq] or NULL
+  const struct ::sann_config *configs;
+  const int64_t *scan_offsets;      // [nq+1] or NULL
+  const int32_t *scan_cluster_ids;
+  const int32_t *scan_begin;        // [nq] start of the query's region in scan_row / scan_w
+  const int32_t *cluster_ids;       // [n_rows] the index's cluster ids, ascending
+  QueryHdr *hdr;
+  int32_t *scan_row;
+  double *scan_w;
+  int32_t *d_k;
+  int64_t now_ms;
+  int32_t n_rows, n_configs, variant, nq;
+};
+hipError_t launch_prep(const PrepView &in, hipStream_t stream);
 
 hipError_t launch_debug_approx(int alg, int n, const double *s, const double *w, double l2norm, double lognorm, float *out,
                                uint8_t *out_forced, hipStream_t stream);

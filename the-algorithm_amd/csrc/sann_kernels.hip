@@ -582,20 +582,31 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   // key < unit_thr; it cannot belong to the top-k iff unit_thr <= the k-th key.  With fewer than
   // k results there is no k-th key, so any withholding unit makes the result unproven.
   int msz = 0, inexact = 0;
+  uint32_t t_max = 0, t_sum = 0;
   for (int u = tid; u < P; u += WG) {
     const int64_t unit = unit0 + u;
     msz += b.unit_unique[unit];
+    if (b.q_stat) {
+      const uint32_t T = (uint32_t)b.unit_T[unit];
+      t_max = T > t_max ? T : t_max;
+      t_sum += T;
+    }
     if (k > 0 && (b.unit_flags[unit] & UNIT_TRUNCATED)) {
       const uint64_t thi = b.unit_thr[2 * unit], tlo = b.unit_thr[2 * unit + 1];
       if (key_gt(thi, tlo, xk_hi, xk_lo)) inexact = 1;
     }
   }
-  if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
+  if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; }
   __syncthreads();
   if (msz) atomicAdd(&s_ctl[0], msz);
   if (inexact) atomicOr(&s_ctl[1], 1);
+  if (t_sum) {
+    atomicMax((unsigned *)&s_ctl[2], t_max);
+    atomicAdd((unsigned *)&s_ctl[3], t_sum);
+  }
   __syncthreads();
   if (tid == 0) {
+    if (b.q_stat) b.q_stat[q] = make_uint4((unsigned)s_ctl[2], (unsigned)s_ctl[3], (unsigned)h.n_scan, 0u);
     ((int32_t *)((char *)b.out_map_sizes + out_shift))[ql] = s_ctl[0];
     if (s_ctl[1]) {
       int o = atomicAdd(&b.status[1], 1);

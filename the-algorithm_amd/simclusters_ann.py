@@ -95,7 +95,7 @@ class sann_batch_stats_t(C.Structure):
         ("n_units", C.c_int32),
         ("n_fallback_units", C.c_int32),
         ("n_requeried", C.c_int32),
-        ("reserved", C.c_int32),
+        ("max_unit_postings", C.c_int32),
     ]
 
 
@@ -147,6 +147,9 @@ _PROTOS = {
     "sann_index_get_list": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "sann_index_destroy": (C.c_int, [C.c_void_p]),
     "sann_batch_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "sann_batch_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sann_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "sann_host_free": (C.c_int, [C.c_void_p]),
     "sann_batch_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sann_batch_run_after": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "sann_batch_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -356,8 +359,17 @@ class QueryBatch:
     def __init__(self, index: ClusterTweetIndex, emb_offsets, emb_cluster_ids, emb_scores, configs, *, now_ms: int,
                  variant: Variant = Variant.original, source_tweet_ids=None, has_source_tweet=None,
                  scan_offsets=None, scan_cluster_ids=None):
-        lib = load_library()
         self.index = index
+        self.variant = variant
+        self._h = C.c_void_p()
+        args = self._pack(emb_offsets, emb_cluster_ids, emb_scores, configs, source_tweet_ids, has_source_tweet,
+                          scan_offsets, scan_cluster_ids)
+        h = C.c_void_p()
+        _check(load_library().sann_batch_create(index.handle, int(variant), int(now_ms), *args, C.byref(h)))
+        self._h = h
+
+    def _pack(self, emb_offsets, emb_cluster_ids, emb_scores, configs, source_tweet_ids, has_source_tweet, scan_offsets,
+              scan_cluster_ids):
         self.nq = len(emb_offsets) - 1
         self._keep = [
             np.ascontiguousarray(emb_offsets, np.int64),
@@ -372,13 +384,17 @@ class QueryBatch:
             configs = [configs]
         self.configs = list(configs)
         carr = (sann_config_t * len(self.configs))(*[c.to_c() for c in self.configs])
-        h = C.c_void_p()
-        k = self._keep
-        _check(lib.sann_batch_create(index.handle, int(variant), int(now_ms), self.nq, _ptr(k[0]), _ptr(k[1]), _ptr(k[2]),
-                                     _ptr(k[3]), _ptr(k[4]), C.cast(carr, C.c_void_p), len(self.configs), _ptr(k[5]),
-                                     _ptr(k[6]), C.byref(h)))
-        self._h = h
         self.stride = max(1, max(min(max(c.maxNumResults, 0), 1000) for c in self.configs))
+        k = self._keep
+        return (self.nq, _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(k[3]), _ptr(k[4]), C.cast(carr, C.c_void_p),
+                len(self.configs), _ptr(k[5]), _ptr(k[6]))
+
+    def reset(self, emb_offsets, emb_cluster_ids, emb_scores, configs, *, now_ms: int, stream: int = 0,
+              source_tweet_ids=None, has_source_tweet=None, scan_offsets=None, scan_cluster_ids=None):
+        """sann_batch_reset: new queries into the same batch object (buffers kept); run() must follow on `stream`."""
+        args = self._pack(emb_offsets, emb_cluster_ids, emb_scores, configs, source_tweet_ids, has_source_tweet,
+                          scan_offsets, scan_cluster_ids)
+        _check(load_library().sann_batch_reset(self._h, C.c_void_p(stream), int(now_ms), *args))
 
     def run(self, stream: int = 0):
         _check(load_library().sann_batch_run(self._h, C.c_void_p(stream)))
@@ -452,6 +468,60 @@ class QueryBatch:
             self.close()
         except Exception:
             pass
+
+
+def pinned_array(shape, dtype) -> np.ndarray:
+    """A numpy array over pinned host memory (sann_host_alloc): request / response buffers a front end keeps across
+    calls.  The memory is released when the array (and every view of it) is garbage-collected."""
+    lib = load_library()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = C.c_void_p()
+    _check(lib.sann_host_alloc(max(n, 1), C.byref(p)))
+
+    class _Owner:
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+        def __del__(self):
+            try:
+                lib.sann_host_free(C.c_void_p(self.ptr))
+            except Exception:
+                pass
+
+    buf = (C.c_char * max(n, 1)).from_address(p.value)
+    buf._owner = _Owner(p.value)  # the ctypes object keeps the allocation alive; numpy keeps the ctypes object
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+
+def get_tweet_candidates(index: ClusterTweetIndex, emb_offsets, emb_cluster_ids, emb_scores, configs, *, now_ms: int,
+                         variant: Variant = Variant.original, source_tweet_ids=None, has_source_tweet=None,
+                         scan_offsets=None, scan_cluster_ids=None, out=None):
+    """sann_get_tweet_candidates: host arrays in, host arrays out, one call (what the JNI stub of INTEGRATION.md
+    binds).  `out` = (ids[nq, stride], scores[nq, stride], counts[nq], map_sizes[nq]) to reuse response buffers
+    (e.g. pinned_array); returns that tuple."""
+    lib = load_library()
+    if isinstance(configs, SimClustersANNConfig):
+        configs = [configs]
+    configs = list(configs)
+    carr = (sann_config_t * len(configs))(*[c.to_c() for c in configs])
+    eo = np.ascontiguousarray(emb_offsets, np.int64)
+    ec = np.ascontiguousarray(emb_cluster_ids, np.int32)
+    es = np.ascontiguousarray(emb_scores, np.float64)
+    src = None if source_tweet_ids is None else np.ascontiguousarray(source_tweet_ids, np.int64)
+    has = None if has_source_tweet is None else np.ascontiguousarray(has_source_tweet, np.uint8)
+    so = None if scan_offsets is None else np.ascontiguousarray(scan_offsets, np.int64)
+    sc = None if scan_cluster_ids is None else np.ascontiguousarray(scan_cluster_ids, np.int32)
+    nq = len(eo) - 1
+    stride = max(1, max(min(max(c.maxNumResults, 0), 1000) for c in configs))
+    if out is None:
+        out = (np.zeros((nq, stride), np.int64), np.zeros((nq, stride), np.float64), np.zeros(nq, np.int32), np.zeros(nq, np.int32))
+    ids, scores, counts, msz = out
+    assert ids.shape[0] >= nq and ids.shape[1] >= stride and ids.shape == scores.shape
+    _check(lib.sann_get_tweet_candidates(index.handle, int(variant), int(now_ms), nq, _ptr(eo), _ptr(ec), _ptr(es), _ptr(src),
+                                         _ptr(has), C.cast(carr, C.c_void_p), len(configs), _ptr(so), _ptr(sc), _ptr(ids),
+                                         _ptr(scores), ids.shape[1], _ptr(counts), _ptr(msz)))
+    return out
 
 
 class ApproximateCosineSimilarity:
