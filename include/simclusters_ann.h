@@ -241,6 +241,12 @@ int sann_batch_desc_time(sann_batch_t *batch, double *desc_ms_total);
  * buffer; enable=0 returns the averages (avg16[0] = whole unit, avg16[i] = phase i, shader
  * clocks, avg16[15] = units counted) and frees the buffer.  Never quote a run timed this way. */
 int sann_debug_phase_cycles(sann_batch_t *batch, int32_t enable, double *avg16);
+/* Measurement only: the fast unit kernel's memory side on its own (same grid, descriptors and posting gather, a
+ * checksum instead of the arithmetic), averaged over `reps` launches after a batch has run.  mode 0 = one workgroup
+ * per unit, as the unit kernel; mode 1 = persistent workgroups (wgs_per_cu per CU) that load the next unit's postings
+ * before they consume the current one.  *checksum is the same for both modes. */
+int sann_debug_gather_probe(sann_batch_t *batch, int32_t mode, int32_t wgs_per_cu, int32_t reps, double *ms_avg,
+                            uint64_t *checksum);
 /* Debug: after sann_batch_run + a device sync and BEFORE sann_batch_finish, histogram of why fast
  * units overflowed: [1] too many scanned clusters, [2] too many postings, [3] too many
  * multi-cluster tweets, [4] score outside the fp32 pre-filter range / hash clash, [5] tie group. */
@@ -320,6 +326,9 @@ int sann_batch_device_k(sann_batch_t *batch, void **d_k);
 int sann_debug_normalise(int32_t device, int32_t alg, int32_t n, const double *dot, const double *nsq, double l2norm,
                          double lognorm, double *out);
 
+/* Audit hook: values[64 * n_waves] -- every group of 64 is sorted descending in place by one wavefront with the unit
+ * kernel's in-register bitonic network (quad permutes, row shifts, gfx950 row / half-wave swaps). */
+int sann_debug_wave_sort(int32_t device, int32_t n_waves, uint32_t *values);
 /* Audit hook: the fp32 pre-filter score the fast unit kernel gives a single-cluster candidate (posting score s[i],
  * cluster weight w[i]) under `alg`, by the same device function; out_forced[i] = 1 where the exact score is +inf / NaN
  * and the candidate is kept unconditionally.  *eps receives the bound the kernel's cut assumes on

@@ -61,6 +61,20 @@ def test_prefilter_error_bound(pkg, alg):
     assert rel.max() < 1.5e-6  # the actual error, well inside the 4e-6 the cut assumes
 
 
+def test_wave_sort_network(pkg):
+    """The in-register 64-lane bitonic network of the cut (DPP quad permutes / row shifts, v_permlane16/32_swap)."""
+    lib = pkg.load_library()
+    rng = np.random.default_rng(9)
+    v = rng.integers(0, 2 ** 32, size=(500, 64), dtype=np.uint64).astype(np.uint32)
+    v[:50] = rng.integers(0, 5, size=(50, 64)).astype(np.uint32)  # heavy ties
+    v[50] = 0
+    v[51] = np.arange(64, dtype=np.uint32)
+    want = -np.sort(-v.astype(np.int64), axis=1)
+    got = np.ascontiguousarray(v.copy())
+    assert lib.sann_debug_wave_sort(0, got.shape[0], got.ctypes.data_as(C.c_void_p)) == 0, lib.sann_last_error()
+    assert np.array_equal(got.astype(np.int64), want)
+
+
 def _tiny_score_corpus(pkg, seed, lo_exp):
     """The small test corpus with every posting score scaled by 10^-U(0, lo_exp) (decay), lists re-sorted by score
     descending as the store would return them."""

@@ -1178,6 +1178,43 @@ int sann_debug_phase_cycles(sann_batch_t *b, int32_t enable, double *avg16) {
   return SANN_OK;
 }
 
+int sann_debug_gather_probe(sann_batch_t *b, int32_t mode, int32_t wgs_per_cu, int32_t reps, double *ms_avg,
+                            uint64_t *checksum) {
+  if (!b || !ms_avg || !checksum) return fail(SANN_EINVAL, "NULL argument");
+  if (!b->ran || !b->use_fast) return fail(SANN_EINVAL, "run the batch on the fast path first");
+  if (reps < 1 || wgs_per_cu < 1 || wgs_per_cu > 16) return fail(SANN_EINVAL, "bad reps / wgs_per_cu");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  HIP_TRY(hipDeviceSynchronize());
+  DevBuf out;
+  HIP_TRY(out.alloc((size_t)std::max(b->n_units, 1) * 8));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  float total = 0.f;
+  for (int r = 0; r <= reps; r++) {  // rep 0 = warm-up
+    HIP_TRY(hipMemsetAsync(out.p, 0, out.bytes, nullptr));
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    if (mode >= 10) HIP_TRY(launch_unit_ablation(b->ix->view(), b->view(), b->fast, mode - 10, nullptr));
+    else
+      HIP_TRY(launch_gather_probe(b->ix->view(), b->view(), b->fast.unit_capacity, mode, wgs_per_cu,
+                                  out.as<unsigned long long>(), nullptr));
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (r) total += ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  std::vector<uint64_t> h((size_t)b->n_units);
+  HIP_TRY(hipMemcpy(h.data(), out.p, h.size() * 8, hipMemcpyDeviceToHost));
+  uint64_t x = 0;
+  for (size_t i = 0; i < h.size(); i++) x ^= h[i] * (2 * i + 1);
+  *checksum = x;
+  *ms_avg = total / reps;
+  return SANN_OK;
+}
+
 int sann_debug_overflow_reasons(sann_batch_t *b, int32_t *counts8, int32_t *n_inexact) {
   if (!b || !counts8) return fail(SANN_EINVAL, "NULL argument");
   HIP_TRY(hipSetDevice(b->ix->device));
@@ -1326,6 +1363,18 @@ int sann_merge_shards_cut(int32_t device, void *hip_stream, int32_t n_shards, in
                               (const int32_t *)d_counts, (const int32_t *)d_map_sizes, nullptr, k, shard_k, out_stride,
                               (int64_t *)d_out_ids, (double *)d_out_scores, (int32_t *)d_out_counts,
                               (int32_t *)d_out_map_sizes, (int32_t *)d_inexact_count, (hipStream_t)hip_stream));
+  return SANN_OK;
+}
+
+int sann_debug_wave_sort(int32_t device, int32_t n_waves, uint32_t *values) {
+  if (n_waves < 0 || (n_waves > 0 && !values)) return fail(SANN_EINVAL, "bad arguments");
+  if (n_waves == 0) return SANN_OK;
+  HIP_TRY(hipSetDevice(device));
+  DevBuf d;
+  HIP_TRY(d.alloc((size_t)n_waves * 64 * 4));
+  HIP_TRY(hipMemcpy(d.p, values, (size_t)n_waves * 64 * 4, hipMemcpyHostToDevice));
+  HIP_TRY(launch_debug_wave_sort(n_waves, d.as<uint32_t>(), nullptr));
+  HIP_TRY(hipMemcpy(values, d.p, (size_t)n_waves * 64 * 4, hipMemcpyDeviceToHost));
   return SANN_OK;
 }
 

@@ -200,6 +200,43 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
 }
 __device__ inline uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
 
+// Value of lane (l ^ J), without a trip through the LDS crossbar (a chain of 21 ds_bpermute round trips cost the
+// sort below ~6k cycles of latency): quad permutes, row shifts, and gfx950's row / half-wave swaps.
+template <int J>
+__device__ inline uint32_t lane_xor(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+  if constexpr (J == 1) return dpp_u32<0xB1, 0xf>(v, v);  // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return dpp_u32<0x4E, 0xf>(v, v);  // quad_perm [2,3,0,1]
+  else if constexpr (J == 4 || J == 8) {
+    const uint32_t up = dpp_u32<0x100 + J, 0xf>(v, v);    // row_shl:J  -> lane l reads l + J
+    const uint32_t down = dpp_u32<0x110 + J, 0xf>(v, v);  // row_shr:J  -> lane l reads l - J
+    return (lane & J) ? down : up;
+  } else if constexpr (J == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // r[0] = rows (0,0,2,2), r[1] = rows (1,1,3,3)
+    return (lane & 16) ? r[0] : r[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // r[0] = halves (lo,lo), r[1] = (hi,hi)
+    return (lane & 32) ? r[0] : r[1];
+  }
+}
+template <int K, int J>
+__device__ inline uint32_t bitonic_step(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t o = lane_xor<J>(v);
+  const bool keep_max = ((lane & K) == 0) == ((lane & J) == 0);
+  return keep_max ? (v > o ? v : o) : (v < o ? v : o);
+}
+// bitonic sort of one value per lane, descending: lane i ends up with the wave's i-th largest
+__device__ inline uint32_t wave_sort_desc_u32(uint32_t v) {
+  v = bitonic_step<2, 1>(v);
+  v = bitonic_step<4, 2>(v); v = bitonic_step<4, 1>(v);
+  v = bitonic_step<8, 4>(v); v = bitonic_step<8, 2>(v); v = bitonic_step<8, 1>(v);
+  v = bitonic_step<16, 8>(v); v = bitonic_step<16, 4>(v); v = bitonic_step<16, 2>(v); v = bitonic_step<16, 1>(v);
+  v = bitonic_step<32, 16>(v); v = bitonic_step<32, 8>(v); v = bitonic_step<32, 4>(v); v = bitonic_step<32, 2>(v); v = bitonic_step<32, 1>(v);
+  v = bitonic_step<64, 32>(v); v = bitonic_step<64, 16>(v); v = bitonic_step<64, 8>(v); v = bitonic_step<64, 4>(v); v = bitonic_step<64, 2>(v); v = bitonic_step<64, 1>(v);
+  return v;
+}
+
 constexpr int bloom_log2(int capacity) { return capacity <= 512 ? 8 : capacity <= 1024 ? 9 : 11; }
 
 enum {
@@ -209,7 +246,14 @@ enum {
 
 // second launch bound = waves per SIMD: small units are asked to fit 8 waves (<= 64 VGPRs); the
 // rare duplicate-resolution code may spill, the common path does not
-template <int WG, int U>
+// ABL != 0: measurement builds that stop after a phase (sann_debug_gather_probe modes 11..15; results are garbage)
+#define ABLATE(n, expr)                                                                                      \
+  if constexpr (ABL == (n)) {                                                                                \
+    unsigned long long sink_ = (expr);                                                                       \
+    if (sink_ == 0x123456789abcdefull) b.unit_thr[2 * (int64_t)unit] = sink_;                                \
+    return;                                                                                                  \
+  }
+template <int WG, int U, int ABL = 0>
 __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 8 ? 5 : 3)) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
   constexpr int SCAP = FAST_SCAP;
   constexpr int BW = bloom_log2(WG * U);  // log2 of the Bloom filter's 64-bit words
@@ -224,20 +268,19 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
   __shared__ uint8_t s_map[WG * U];  // flat posting index -> cluster sequence number
   __shared__ double s_w[NSCAN_MAX];
   __shared__ float s_w32[NSCAN_MAX];
+  __shared__ uint32_t s_wkey[NSCAN_MAX];  // cosine forms: the fp32 key of a single-cluster candidate of the cluster (0 = untrusted)
   __shared__ unsigned long long s_fbloom[FBLOOM_WORDS];
   __shared__ long long s_Mid[MCAP];
   __shared__ int s_Mseq[MCAP], s_Mrole[MCAP];
   __shared__ double s_Msc[MCAP], s_Mdot[MCAP], s_Mnsq[MCAP];
   // The survivor list and the radix histogram are first touched after the duplicate phase, when the Bloom filter is
   // dead: with a filter of >= 1024 words they live in its memory (barriers at the end of phase 3 lie between).
-  constexpr bool ALIAS = BLOOM_ALLOC >= 3 * SCAP + 128;
-  __shared__ long long s_sid_own[ALIAS ? 1 : SCAP];
-  __shared__ double s_sdot_own[ALIAS ? 1 : SCAP], s_snsq_own[ALIAS ? 1 : SCAP];
+  constexpr bool ALIAS = BLOOM_ALLOC >= SCAP + 128;
+  __shared__ unsigned long long s_ent_own[ALIAS ? 1 : SCAP];
   __shared__ unsigned s_hist_own[ALIAS ? 1 : 256];
-  long long *const s_sid = ALIAS ? reinterpret_cast<long long *>(s_bloom) : s_sid_own;
-  double *const s_sdot = ALIAS ? reinterpret_cast<double *>(s_bloom + SCAP) : s_sdot_own;
-  double *const s_snsq = ALIAS ? reinterpret_cast<double *>(s_bloom + 2 * SCAP) : s_snsq_own;
-  unsigned *const s_hist = ALIAS ? reinterpret_cast<unsigned *>(s_bloom + 3 * SCAP) : s_hist_own;
+  // survivor list: (cluster sequence number or 0x10000 | match-list entry) << 32 | position of the posting in the index
+  unsigned long long *const s_ent = ALIAS ? s_bloom : s_ent_own;
+  unsigned *const s_hist = ALIAS ? reinterpret_cast<unsigned *>(s_bloom + SCAP) : s_hist_own;
   __shared__ int s_ctl[CTL_N];
 
   const int tid = threadIdx.x;
@@ -264,6 +307,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
   // the descriptor loads are issued (a branch on T first cost a second, serial trip to memory).
   // (Tv stays a per-lane register until after the loop: a scalar copy would make hipcc wait for it right here)
   uint32_t Tv = overflow_n ? 0u : (uint32_t)b.unit_T[unit];
+  const float inv_l2_32 = (float)(1.0 / h.l2norm);
   if (!overflow_n) {
     const uint32_t *d = b.desc + 2 * ((int64_t)h.scan_begin * ix.P + (int64_t)p * h.n_scan);
     // four lanes per cluster: lane part (0..3) fills a quarter of the cluster's stretch of the map
@@ -278,6 +322,8 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
         s_pre[c] = v.y;
         s_w[c] = w;
         s_w32[c] = (float)w;
+        const float wn = h.alg == 2 ? (float)w * inv_l2_32 : (float)w;
+        s_wkey[c] = (wn > 1e-30f && wn < 1e30f) ? (__float_as_uint(wn) | 0x80000000u) : 0u;
       }
       // every posting of this cluster records its cluster in the flat map (an oversized unit stops at the map's end)
       asm volatile("" : "+v"(nxt));  // keeps the select on Tv below the loads above
@@ -294,71 +340,106 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
   __syncthreads();
   STAMP(1);  // descriptors + map done
 
-  // ---- 2. gather (postings stay in registers) -------------------------------------------------
-  long long id[U];
-  double sc[U];  // posting score
-  int seq[U];    // cluster sequence number; bit 16 = group representative; < 0 = no candidate here
+  // ---- 2. gather ---------------------------------------------------------------------------------------
+  // A posting is looked at ONCE: window / source filters on its id, three Bloom bits from a hash of its id, and its
+  // score rounded to fp32 for the pre-filter.  What stays in registers per posting is 12 bytes -- (s32, cluster, hash)
+  // -- not the 16-byte posting: the few that survive the cut (~4 %) are fetched again (from L2) for their exact
+  // fp64 arithmetic.  With the 16-byte form resident, six slots did not fit 80 registers and hipcc kept two of them
+  // in scratch memory, re-reading them in every later phase.
+  float s32[U];   // posting score, fp32
+  int seq[U];     // cluster sequence number; bit 16 = group representative (low bits: match-list entry); < 0 = no candidate here
+  uint32_t hsh[U];  // table_hash of the tweet id (Bloom word and bits; dead after the duplicate phase)
   int live = 0;
 #pragma unroll
   for (int u = 0; u < U; u++) {
     seq[u] = -1;
-    id[u] = 0;
-    sc[u] = 0.0;
+    s32[u] = 0.f;
+    hsh[u] = 0u;
   }
   {
     // an overflowed unit gathers nothing: with Tg = 0 every slot below is skipped, and no separate control path
     // has to be merged with the loaded registers (the merge made hipcc wait for the first slot's load at once)
     const uint32_t Tg = overflow ? 0u : T;
-    Posting pst[U];
+    // The loads are written as inline asm and waited for by hand.  Left to hipcc, the six 16-byte loads of a thread
+    // were given OVERLAPPING destination registers (the id half of one under the score half of the next) with an
+    // `s_waitcnt vmcnt(0)` + register copy behind every one of them: six serial trips to memory instead of one.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 raw[U];
+    // Every slot loads, unconditionally (a slot the unit does not reach re-reads the unit's last posting: one cache
+    // line for the whole wave): the asm outputs then have no other definition they would have to be merged with --
+    // a merge is a register copy placed right behind the load, i.e. a read of registers the load has not written yet.
+    if (Tg != 0u) {
 #pragma unroll
-    for (int uu = 0; uu < U; uu++) {
-      const int u = U - 1 - uu;  // last slot first (see the note at the second loop)
-      if ((uint32_t)(u * WG) < Tg) {  // uniform: skip register slots the unit does not reach (pst[u] stays unset, unused)
-        // lanes past the end re-read the unit's last posting (dead: seq = -1): an unconditional load keeps the
-        // slots' loads free of per-lane control flow, so all of them are in flight before the first is used
+      for (int u = 0; u < U; u++) {
         const uint32_t j = (uint32_t)(u * WG + tid);
         const uint32_t jj = j < Tg ? j : Tg - 1;
         const int c = (int)s_map[jj];
         seq[u] = (j < Tg) ? c : -1;
-        pst[u] = ix.postings[s_begin[c] + (jj - s_pre[c])];
+        const Posting *src = ix.postings + (s_begin[c] + (jj - s_pre[c]));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[u]) : "v"(src) : "memory");
       }
-    }
     STAMP(2);  // posting loads issued
-    // the same bound, made opaque: hipcc otherwise threads each slot's "use" block onto its "issue" block (same
-    // uniform condition) and, for slot 0, waited for that slot's load before the other loads were even issued
-    uint32_t Tu = Tg;
-    asm volatile("" : "+s"(Tu));
+    if constexpr (U == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]) : : "memory");
+    else if constexpr (U == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) : : "memory");
+    else if constexpr (U == 6)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]) : : "memory");
+    else {
+#pragma unroll
+      for (int u0 = 0; u0 < U; u0 += 4)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[u0]), "+v"(raw[u0 + 1]), "+v"(raw[u0 + 2]), "+v"(raw[u0 + 3]) : : "memory");
+    }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if ((uint32_t)(u * WG) < Tu) {
+      if ((uint32_t)(u * WG) < Tg) {
         // NB: selects, not `seq[u] = -1; continue;` -- hipcc (ROCm 7.2) mis-structurised that form
         // and dropped the -1 for postings outside the age window.
         const bool have = seq[u] >= 0;
-        id[u] = pst[u].id;
-        sc[u] = pst[u].score;
-        const bool excluded = h.excl_enabled != 0 && id[u] == h.src_excl;  // :90
-        const bool in_window = id[u] >= h.earliest && id[u] <= h.latest;   // :91
+        const long long idv = (long long)(((unsigned long long)raw[u].y << 32) | raw[u].x);
+        const double scv = __longlong_as_double((long long)(((unsigned long long)raw[u].w << 32) | raw[u].z));
+        const bool excluded = h.excl_enabled != 0 && idv == h.src_excl;  // :90
+        const bool in_window = idv >= h.earliest && idv <= h.latest;     // :91
         const bool keep = have && !excluded && in_window;
         seq[u] = keep ? seq[u] : -1;
+        s32[u] = (float)scv;
         live += __popcll(__ballot(keep));  // wave count, identical in all lanes
-        if (keep) {
-          // ---- 3a. blocked Bloom filter: three bits of one 64-bit word, one atomic ------------
-          const uint32_t hsh = table_hash(id[u], HB);
-          const unsigned long long bits =
-              (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63)) | (1ull << ((hsh >> 12) & 63));
-          const unsigned long long old = atomicOr(&s_bloom[hsh >> 18], bits);
-          if ((old & bits) == bits) {
-            // possibly seen before: mark the id's bits in the (sparse) "flagged" filter
-            atomicOr(&s_fbloom[hsh >> (HB - FB)], bits);
-            s_ctl[CTL_NFLAG] = 1;
-          }
-        }
+        hsh[u] = table_hash(idv, HB);
+      }
+    }
+    }
+    // ---- 3a. blocked Bloom filter: three bits of one 64-bit word, one returning LDS atomic per posting.  All of a
+    // thread's atomics are issued before the first result is looked at (one LDS round trip, not U).
+    unsigned long long seen[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      seen[u] = 0ull;
+      if ((uint32_t)(u * WG) < Tg && seq[u] >= 0) {
+        const uint32_t hv = hsh[u];
+        const unsigned long long bits = (1ull << (hv & 63)) | (1ull << ((hv >> 6) & 63)) | (1ull << ((hv >> 12) & 63));
+        seen[u] = ~atomicOr(&s_bloom[hv >> 18], bits) & bits;  // bits of this posting that were NOT set before
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if ((uint32_t)(u * WG) < Tg && seq[u] >= 0 && seen[u] == 0ull) {
+        // possibly seen before: mark the id's bits in the (sparse) "flagged" filter
+        const uint32_t hv = hsh[u];
+        const unsigned long long bits = (1ull << (hv & 63)) | (1ull << ((hv >> 6) & 63)) | (1ull << ((hv >> 12) & 63));
+        atomicOr(&s_fbloom[hv >> (HB - FB)], bits);
+        s_ctl[CTL_NFLAG] = 1;
       }
     }
     if ((tid & 63) == 0 && live) atomicAdd(&s_ctl[CTL_LIVE], live);
   }
   __syncthreads();
   STAMP(3);  // postings arrived, filtered, bloom done
+  {
+    unsigned long long x_ = 0;
+    if constexpr (ABL == 1) {
+#pragma unroll
+      for (int u = 0; u < U; u++) x_ ^= (unsigned long long)__float_as_uint(s32[u]) ^ ((unsigned long long)hsh[u] << 32) ^ (unsigned)seq[u];
+    }
+    ABLATE(1, x_ + (unsigned)s_ctl[CTL_NFLAG] + (unsigned)s_ctl[CTL_LIVE]);
+  }
 
   // ---- 3b. resolve flagged ids ------------------------------------------------------------------
   // Every posting whose bits are all set in the flagged filter (the flagged posting itself, the
@@ -370,16 +451,17 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
     for (int u = 0; u < U; u++) {
       mi[u] = -1;
       if (seq[u] >= 0) {
-        const uint32_t hsh = table_hash(id[u], HB);
-        const unsigned long long bits =
-            (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63)) | (1ull << ((hsh >> 12) & 63));
-        if ((s_fbloom[hsh >> (HB - FB)] & bits) == bits) {
+        const uint32_t hv = hsh[u];
+        const unsigned long long bits = (1ull << (hv & 63)) | (1ull << ((hv >> 6) & 63)) | (1ull << ((hv >> 12) & 63));
+        if ((s_fbloom[hv >> (HB - FB)] & bits) == bits) {
           const int m = atomicAdd(&s_ctl[CTL_NM], 1);
           mi[u] = m;
           if (m < MCAP) {
-            s_Mid[m] = id[u];
-            s_Mseq[m] = seq[u];
-            s_Msc[m] = sc[u];
+            const int c = seq[u];
+            const Posting pm = ix.postings[s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c])];  // the posting itself, again
+            s_Mid[m] = pm.id;
+            s_Mseq[m] = c;
+            s_Msc[m] = pm.score;
           }
         }
       }
@@ -524,47 +606,107 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
   }
 
   STAMP(4);  // duplicates resolved
-  // ---- 4. approximate fp32 scores and the cut ------------------------------------------------------
+  {
+    unsigned long long x_ = 0;
+    if constexpr (ABL == 2) {
+#pragma unroll
+      for (int u = 0; u < U; u++) x_ ^= (unsigned long long)__float_as_uint(s32[u]) ^ (unsigned)seq[u];
+    }
+    ABLATE(2, x_ + (unsigned)s_ctl[CTL_LIVE]);
+  }
+  // ---- 4. approximate fp32 keys ---------------------------------------------------------------------------
+  // One uniform branch per algorithm around the slot loop (not a switch per slot).  Cosine and the no-source-norm
+  // form need no arithmetic at all for a single-cluster candidate: (s w) / sqrt(s s) = w for s > 0, so the key is a
+  // constant of the cluster (s_wkey, filled with the descriptors).  Representatives of multi-cluster tweets (rare)
+  // are re-keyed afterwards by the general formula.
   uint32_t k32[U];
   {
-    const float invl2 = (float)(1.0 / h.l2norm), invln = (float)(1.0 / h.lognorm);
-    uint32_t kmin = 0xffffffffu, kmax = 0u;
     bool bad = false;
+    if (overflow) {
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      k32[u] = 0;
-      if ((uint32_t)(u * WG) < T && !overflow) {
+      for (int u = 0; u < U; u++) k32[u] = 0u;
+    } else if (h.alg == 2 || h.alg == 4) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
         const bool lv = seq[u] >= 0;
-        float d32, n32;
-        double nsq64;
-        if (lv && (seq[u] & 0x10000)) {
-          nsq64 = s_Mnsq[seq[u] & 0xffff];
-          d32 = (float)s_Mdot[seq[u] & 0xffff];
-          n32 = (float)nsq64;
-        } else {
-          const float s32 = (float)sc[u];
-          nsq64 = sc[u] * sc[u];
-          d32 = s32 * s_w32[lv ? (seq[u] & 0xffff) : 0];
-          n32 = s32 * s32;
-        }
-        bool forced;
-        const float a = approx_score(h.alg, d32, n32, nsq64, invl2, invln, &forced);
-        // the fp32 shortcut is only trusted for ordinary positive magnitudes
-        bad = bad || (lv && !forced && !(a > 1e-30f && a < 1e30f && n32 > 1e-30f && n32 < 1e30f));
-        const uint32_t k = lv ? (forced ? FORCED_KEY : (__float_as_uint(a) | 0x80000000u)) : 0u;
-        k32[u] = k;
-        kmin = lv && k < kmin ? k : kmin;
-        kmax = lv && k > kmax ? k : kmax;
+        const uint32_t wk = s_wkey[lv ? (seq[u] & (NSCAN_MAX - 1)) : 0];
+        // the shortcut is only trusted for ordinary positive magnitudes (s32^2 within the fp32 range, w / l2norm too)
+        bad = bad || (lv && !(seq[u] & 0x10000) && !(s32[u] > 1e-15f && s32[u] < 1e15f && wk != 0u));
+        k32[u] = lv ? wk : 0u;
       }
     }
-    for (int i = tid; i < 256; i += WG) s_hist[i] = 0;  // for the first histogram pass of phase 5 (the Bloom filter is dead)
-    const uint32_t wmin = wave_min_u32(kmin), wmax = wave_max_u32(kmax);
-    const bool wbad = __ballot(bad) != 0ull;
-    if ((tid & 63) == 0) {
-      atomicMin((unsigned *)&s_ctl[CTL_KMIN], wmin);
-      atomicMax((unsigned *)&s_ctl[CTL_KMAX], wmax);
-      if (wbad) atomicOr(&s_ctl[CTL_BAD], 1);
+#ifndef SANN_EXP_COS_ONLY
+    else if (h.alg == 1) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const bool lv = seq[u] >= 0;
+        const float a = s32[u] * s_w32[lv ? (seq[u] & (NSCAN_MAX - 1)) : 0];
+        bad = bad || (lv && !(seq[u] & 0x10000) && !(a > 1e-30f && a < 1e30f));
+        k32[u] = lv ? (__float_as_uint(a) | 0x80000000u) : 0u;
+      }
+    } else {
+      const float invln = (float)(1.0 / h.lognorm);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const bool lv = seq[u] >= 0;
+        const float sv = s32[u];
+        float a = 0.f;
+        bool forced = false;
+        if (lv && !(seq[u] & 0x10000)) {
+          // below 1e-6 the exact form's rounding of 1 + nsq decides the score: that needs the fp64 score, fetched again
+          double nsq64 = 0.0;
+          if (sv * sv < 1e-6f) {
+            const int c = seq[u];
+            const double sd = ix.postings[s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c])].score;
+            nsq64 = sd * sd;
+          }
+          a = approx_score(3, sv * s_w32[seq[u] & (NSCAN_MAX - 1)], sv * sv, nsq64, 0.f, invln, &forced);
+        }
+        bad = bad || (lv && !(seq[u] & 0x10000) && !forced && !(a > 1e-30f && a < 1e30f && sv > 1e-15f && sv < 1e15f));
+        k32[u] = lv ? (forced ? FORCED_KEY : (__float_as_uint(a) | 0x80000000u)) : 0u;
+      }
     }
+    if (!overflow && s_ctl[CTL_NFLAG] != 0) {  // uniform: only units that resolved duplicates can hold representatives
+      const float invl2 = (float)(1.0 / h.l2norm), invln = (float)(1.0 / h.lognorm);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (seq[u] >= 0 && (seq[u] & 0x10000)) {
+          const double nsq64 = s_Mnsq[seq[u] & 0xffff];
+          const float d32 = (float)s_Mdot[seq[u] & 0xffff], n32 = (float)nsq64;
+          bool forced;
+          const float a = approx_score(h.alg, d32, n32, nsq64, invl2, invln, &forced);
+          bad = bad || (!forced && !(a > 1e-30f && a < 1e30f && n32 > 1e-30f && n32 < 1e30f));
+          k32[u] = forced ? FORCED_KEY : (__float_as_uint(a) | 0x80000000u);
+        }
+      }
+    }
+#endif
+    if (__ballot(bad) != 0ull && (tid & 63) == 0) atomicOr(&s_ctl[CTL_BAD], 1);
+  }
+  const int n_live = s_ctl[CTL_LIVE];
+  int kl;
+  {
+    const float share = (float)h.k / (float)ix.P;
+    kl = (int)(share + 6.0f * sqrtf(share) + 8.0f);
+    if (kl < k_local_floor) kl = k_local_floor;
+    if (kl > h.k) kl = h.k;
+    if (kl > SCAP - 32) kl = SCAP - 32;
+  }
+  const int keep_all = SCAP < kl + kl / 2 + 16 ? SCAP : kl + kl / 2 + 16;
+  // ---- 5a. the cut: the kl-th largest LANE MAXIMUM ---------------------------------------------------------------
+  // kl distinct candidates reach the kl-th largest of the 256 per-thread maxima, so cutting there keeps at least kl;
+  // the few candidates that share a thread with a larger one come on top (about U * kl^2 / n_live: 48 in all at the
+  // benchmark's shape), far below the SCAP the survivor list holds.  Each wave sorts its 64 maxima with shuffles, the
+  // four sorted runs meet in LDS, and every thread ranks its own value by three 6-step searches: two barriers, no
+  // LDS atomics (the radix histogram this replaces spent 25 % of the kernel serialising atomics on the few distinct
+  // keys a near-tie batch has).  A cut that keeps more than SCAP falls back to that histogram (5c).
+  uint32_t *const s_lm = s_hist;  // [WG], in the dead Bloom filter's memory (or s_hist_own, which is WG <= 256 words)
+  const bool select = n_live > keep_all && !overflow;  // uniform
+  if (select) {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int u = 0; u < U; u++) m = k32[u] > m ? k32[u] : m;
+    s_lm[tid] = wave_sort_desc_u32(m);
   }
   __syncthreads();
   if (s_ctl[CTL_BAD] && !overflow) { overflow = true; why = (s_ctl[CTL_BAD] & 2) ? 6 : 4; }
@@ -582,97 +724,152 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
     return;
   }
 
-  STAMP(5);  // approximate scores + min/max
-  const int n_live = s_ctl[CTL_LIVE];
-  int kl;
+  STAMP(5);  // approximate keys, lane maxima sorted
   {
-    const float share = (float)h.k / (float)ix.P;
-    kl = (int)(share + 6.0f * sqrtf(share) + 8.0f);
-    if (kl < k_local_floor) kl = k_local_floor;
-    if (kl > h.k) kl = h.k;
-    if (kl > SCAP - 32) kl = SCAP - 32;
+    unsigned long long x_ = 0;
+    if constexpr (ABL == 3) {
+#pragma unroll
+      for (int u = 0; u < U; u++) x_ ^= (unsigned long long)__float_as_uint(s32[u]) ^ (unsigned)seq[u] ^ k32[u];
+    }
+    ABLATE(3, x_ + s_lm[tid]);
   }
   uint32_t tau = 0;  // survivors: k32 >= tau
-  bool give_up = false;
-  const int keep_all = SCAP < kl + kl / 2 + 16 ? SCAP : kl + kl / 2 + 16;
-  if (n_live > keep_all) {
-    const uint32_t gmin = (uint32_t)s_ctl[CTL_KMIN], gmax = (uint32_t)s_ctl[CTL_KMAX];
-    const uint32_t diff = gmin ^ gmax;
-    if (diff == 0) {
-      give_up = true;  // every approximate score identical and too many of them
-    } else {
-      const int hbit = 31 - __clz((int)diff);
-      int shift = hbit - 7 < 0 ? 0 : hbit - 7;
-      int width = hbit - shift + 1;
-      uint32_t prefix = (hbit == 31) ? 0u : (gmax >> (hbit + 1)) << (hbit + 1);
-      int need = kl, budget = SCAP;
-      for (bool first = true;; first = false) {
-        if (!first) {  // (the first pass finds the histogram cleared before the barrier that ended phase 4)
-          for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
+  if (select) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const uint32_t m = s_lm[tid];
+    int rank = lane;  // position in the total order (value desc, wave asc, lane asc)
+#pragma unroll
+    for (int w2 = 0; w2 < WG / 64; w2++) {
+      if (w2 == wv) continue;
+      const uint32_t *L = s_lm + w2 * 64;
+      int pos = 0;  // entries of wave w2's descending run that come before mine
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1) {
+        const uint32_t v = L[pos + step - 1];
+        const bool before = v > m || (v == m && w2 < wv);
+        pos += before ? step : 0;
+      }
+      {  // 64 entries = 63 reachable by the steps above, plus the last one
+        const uint32_t v = L[63];
+        pos += (pos == 63 && (v > m || (v == m && w2 < wv))) ? 1 : 0;
+      }
+      rank += pos;
+    }
+    if (rank == kl - 1) s_ctl[CTL_SEL_D] = (int)m;  // ranks are a permutation: exactly one thread (none when kl > WG: tau = 0)
+    __syncthreads();
+    tau = (uint32_t)s_ctl[CTL_SEL_D];
+  }
+  STAMP(6);  // threshold found
+  {
+    unsigned long long x_ = 0;
+    if constexpr (ABL == 4) {
+#pragma unroll
+      for (int u = 0; u < U; u++) x_ ^= (unsigned long long)__float_as_uint(s32[u]) ^ (unsigned)seq[u] ^ k32[u];
+    }
+    ABLATE(4, x_ + tau);
+  }
+  // ---- 5b. compact the survivors with their exact (dot, nsq): one LDS atomic per wave ------------------------------
+  for (int attempt = 0;; attempt++) {
+    int total = 0;
+    unsigned long long msk[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      msk[u] = __ballot(k32[u] != 0u && k32[u] >= tau);
+      total += __popcll(msk[u]);
+    }
+    int base = 0;
+    if ((tid & 63) == 0 && total) base = atomicAdd(&s_ctl[CTL_NSURV], total);
+    base = __shfl(base, 0, 64);
+    const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (k32[u] != 0u && k32[u] >= tau) {
+        const int o = base + __popcll(msk[u] & below);
+        if (o < SCAP) {
+          const int c = seq[u];
+          const uint32_t pos = (c & 0x10000) ? 0u : s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c]);
+          s_ent[o] = ((unsigned long long)(uint32_t)c << 32) | pos;
+        }
+      }
+      base += __popcll(msk[u]);
+    }
+    __syncthreads();
+    if (s_ctl[CTL_NSURV] <= SCAP || attempt == 1) break;  // uniform
+    // ---- 5c. (rare) the cut kept too many: MSB-first radix histogram over the 32-bit keys, started at the highest
+    // bit in which the unit's keys differ, for a cut with between kl and SCAP candidates above it
+    {
+      uint32_t kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        kmin = k32[u] != 0u && k32[u] < kmin ? k32[u] : kmin;
+        kmax = k32[u] > kmax ? k32[u] : kmax;
+      }
+      const uint32_t wmin = wave_min_u32(kmin), wmax = wave_max_u32(kmax);
+      for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
+      if ((tid & 63) == 0) {
+        atomicMin((unsigned *)&s_ctl[CTL_KMIN], wmin);
+        atomicMax((unsigned *)&s_ctl[CTL_KMAX], wmax);
+      }
+      if (tid == 0) s_ctl[CTL_NSURV] = 0;
+    }
+    __syncthreads();
+    bool give_up = false;
+    {
+      const uint32_t gmin = (uint32_t)s_ctl[CTL_KMIN], gmax = (uint32_t)s_ctl[CTL_KMAX];
+      const uint32_t diff = gmin ^ gmax;
+      if (diff == 0) {
+        give_up = true;  // every approximate score identical and too many of them
+      } else {
+        const int hbit = 31 - __clz((int)diff);
+        int shift = hbit - 7 < 0 ? 0 : hbit - 7;
+        int width = hbit - shift + 1;
+        uint32_t prefix = (hbit == 31) ? 0u : (gmax >> (hbit + 1)) << (hbit + 1);
+        int need = kl, budget = SCAP;
+        for (bool first = true;; first = false) {
+          if (!first) {
+            for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
+            __syncthreads();
+          }
+          const uint32_t hi_mask = (shift + width >= 32) ? 0u : (~0u << (shift + width));
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const uint32_t k = k32[u];
+            if (k != 0u && (k & hi_mask) == (prefix & hi_mask)) atomicAdd(&s_hist[(k >> shift) & ((1u << width) - 1)], 1u);
+          }
+          __syncthreads();
+          if (tid < 64) wave_find_digit(s_hist, need, &s_ctl[CTL_SEL_D]);  // writes D, A, B
+          __syncthreads();
+          const int d = s_ctl[CTL_SEL_D], A = s_ctl[CTL_SEL_A], B = s_ctl[CTL_SEL_B];
+          prefix |= (uint32_t)d << shift;
+          bool stop = false;
+          if (A + B <= budget) stop = true;
+          else if (shift == 0) { give_up = true; stop = true; }  // too many identical approximations
+          else {
+            need -= A;
+            budget -= A;
+            const int ns2 = shift - 8 < 0 ? 0 : shift - 8;
+            width = shift - ns2;
+            shift = ns2;
+          }
+          if (stop) break;  // uniform; nothing below reuses the histogram or these control words
           __syncthreads();
         }
-        const uint32_t hi_mask = (shift + width >= 32) ? 0u : (~0u << (shift + width));
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const uint32_t k = k32[u];
-          if (k != 0u && (k & hi_mask) == (prefix & hi_mask)) atomicAdd(&s_hist[(k >> shift) & ((1u << width) - 1)], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) wave_find_digit(s_hist, need, &s_ctl[CTL_SEL_D]);  // writes D, A, B
-        __syncthreads();
-        const int d = s_ctl[CTL_SEL_D], A = s_ctl[CTL_SEL_A], B = s_ctl[CTL_SEL_B];
-        prefix |= (uint32_t)d << shift;
-        bool stop = false;
-        if (A + B <= budget) stop = true;
-        else if (shift == 0) { give_up = true; stop = true; }  // too many identical approximations
-        else {
-          need -= A;
-          budget -= A;
-          const int ns = shift - 8 < 0 ? 0 : shift - 8;
-          width = shift - ns;
-          shift = ns;
-        }
-        if (stop) break;  // uniform; nothing below reuses the histogram or these control words
-        __syncthreads();
-      }
-      tau = prefix;
-    }
-  }
-  if (give_up) {
-    if (tid == 0) {
-      b.cand_cnt[unit] = 0;
-      b.unit_unique[unit] = 0;
-      b.unit_flags[unit] = UNIT_OVERFLOW;
-      b.unit_thr[2 * (int64_t)unit] = 0;
-      b.unit_thr[2 * (int64_t)unit + 1] = 5ull;
-      const int o = atomicAdd(&b.status[0], 1);
-      b.overflow_units[o] = unit;
-    }
-    return;
-  }
-
-  STAMP(6);  // threshold found
-  // ---- 5. compact the survivors with their exact (dot, nsq) --------------------------------------
-#pragma unroll
-  for (int u = 0; u < U; u++) {
-    if (k32[u] != 0u && k32[u] >= tau) {
-      double dot, nsq;
-      if (seq[u] & 0x10000) {
-        dot = s_Mdot[seq[u] & 0xffff];
-        nsq = s_Mnsq[seq[u] & 0xffff];
-      } else {
-        dot = 0.0 + sc[u] * s_w[seq[u] & 0xffff];  // getOrElse(tweetId, 0.0) + score * sourceClusterScore
-        nsq = 0.0 + sc[u] * sc[u];
-      }
-      const int o = atomicAdd(&s_ctl[CTL_NSURV], 1);
-      if (o < SCAP) {
-        s_sid[o] = id[u];
-        s_sdot[o] = dot;
-        s_snsq[o] = nsq;
+        tau = prefix;
       }
     }
+    if (give_up) {
+      if (tid == 0) {
+        b.cand_cnt[unit] = 0;
+        b.unit_unique[unit] = 0;
+        b.unit_flags[unit] = UNIT_OVERFLOW;
+        b.unit_thr[2 * (int64_t)unit] = 0;
+        b.unit_thr[2 * (int64_t)unit + 1] = 5ull;
+        const int o = atomicAdd(&b.status[0], 1);
+        b.overflow_units[o] = unit;
+      }
+      return;
+    }
   }
-  __syncthreads();
   const int ns = s_ctl[CTL_NSURV] < SCAP ? s_ctl[CTL_NSURV] : SCAP;
   // theta: every candidate below the cut has approx < tau, hence exact < tau * (1 + 2 EPS)
   unsigned long long theta_key = 0ull;
@@ -685,15 +882,30 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
   }
 
   STAMP(7);  // survivors compacted
-  // ---- 6. exact scores of the survivors, emit ------------------------------------------------------
+  ABLATE(5, (unsigned long long)ns + theta_key + s_ent[tid % SCAP]);
+  // ---- 6. the survivors' postings again (one parallel trip, mostly to L2), exact fp64 scores, emit ------------------
   const int64_t obase = (int64_t)unit * b.cap;
   for (int i = tid; i < ns; i += WG) {
-    const double v = normalise_f(h.alg, s_sdot[i], s_snsq[i], h.l2norm, h.lognorm);
+    const unsigned long long e = s_ent[i];
+    const int c = (int)(e >> 32);
+    long long idv;
+    double dot, nsq;
+    if (c & 0x10000) {
+      idv = s_Mid[c & 0xffff];
+      dot = s_Mdot[c & 0xffff];
+      nsq = s_Mnsq[c & 0xffff];
+    } else {
+      const Posting ps = ix.postings[(uint32_t)e];
+      idv = ps.id;
+      dot = 0.0 + ps.score * s_w[c];  // getOrElse(tweetId, 0.0) + score * sourceClusterScore  (:92-94)
+      nsq = 0.0 + ps.score * ps.score;  // (:95-96)
+    }
+    const double v = normalise_f(h.alg, dot, nsq, h.l2norm, h.lognorm);
     const unsigned long long key = score_key(v);
     if (v >= h.min_score && key >= theta_key) {  // :125 (false for NaN)
       const int o = atomicAdd(&s_ctl[CTL_CNT], 1);
       b.cand_key[obase + o] = key;
-      b.cand_id[obase + o] = s_sid[i];
+      b.cand_id[obase + o] = idv;
     }
   }
   __syncthreads();
@@ -805,6 +1017,33 @@ __global__ void debug_approx_kernel(int alg, int n, const double *s, const doubl
   out[i] = approx_score(alg, s32 * (float)w[i], s32 * s32, s[i] * s[i], invl2, invln, &forced);
   out_forced[i] = forced ? 1 : 0;
 }
+// Audit hook: every wave sorts its 64 values with the unit kernel's wave_sort_desc_u32
+__global__ void debug_wave_sort_kernel(uint32_t *v) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  v[i] = wave_sort_desc_u32(v[i]);
+}
+hipError_t launch_debug_wave_sort(int n_waves, uint32_t *v, hipStream_t stream) {
+  if (n_waves <= 0) return hipSuccess;
+  hipLaunchKernelGGL(debug_wave_sort_kernel, dim3(n_waves), dim3(64), 0, stream, v);
+  return hipGetLastError();
+}
+
+hipError_t launch_unit_ablation(const IndexView &ix, const BatchView &b, const FastParams &fp, int abl, hipStream_t stream) {
+  const int nq8 = (b.nq + 7) / 8 * 8;
+  const int n_blocks = nq8 * ix.P;
+  if (fp.unit_capacity != 1536) return hipErrorInvalidValue;
+  switch (abl) {
+    case 0: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 0>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 1: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 1>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 2: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 2>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 3: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 3>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 4: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 4>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 5: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 5>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_debug_approx(int alg, int n, const double *s, const double *w, double l2norm, double lognorm, float *out,
                                uint8_t *out_forced, hipStream_t stream) {
   if (n <= 0) return hipSuccess;

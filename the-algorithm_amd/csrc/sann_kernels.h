@@ -42,6 +42,10 @@ struct PrepView {
 };
 hipError_t launch_prep(const PrepView &in, hipStream_t stream);
 
+// measurement only (sann_probe.hip): the unit kernel's gather with the arithmetic replaced by a checksum
+hipError_t launch_gather_probe(const IndexView &ix, const BatchView &b, int unit_capacity, int mode, int wgs_per_cu,
+                               unsigned long long *out, hipStream_t stream);
+hipError_t launch_debug_wave_sort(int n_waves, uint32_t *v, hipStream_t stream);
 hipError_t launch_debug_approx(int alg, int n, const double *s, const double *w, double l2norm, double lognorm, float *out,
                                uint8_t *out_forced, hipStream_t stream);
 constexpr double kApproxEps = 4e-6;  // = APPROX_EPS of sann_fast.hip, reported by sann_debug_approx
@@ -56,6 +60,7 @@ struct FastParams {
 };
 hipError_t launch_cut(const IndexView &ix, int M, uint32_t *out, hipStream_t stream);
 hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int max_n_scan, hipStream_t stream);
+hipError_t launch_unit_ablation(const IndexView &ix, const BatchView &b, const FastParams &fp, int abl, hipStream_t stream);
 hipError_t launch_unit_fast(const IndexView &ix, const BatchView &b, const FastParams &fp, int n_units,
                             hipStream_t stream);
 

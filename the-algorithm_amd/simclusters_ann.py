@@ -164,10 +164,12 @@ _PROTOS = {
     "sann_tweet_partition": (C.c_int32, [C.c_int64, C.c_int32]),
     "sann_device_synchronize": (C.c_int, [C.c_int32]),
     "sann_debug_overflow_reasons": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sann_debug_gather_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "sann_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "sann_batch_destroy": (C.c_int, [C.c_void_p]),
     "sann_get_tweet_candidates": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "sann_debug_normalise": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
+    "sann_debug_wave_sort": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p]),
     "sann_debug_approx": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "sann_batch_bind_outputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sann_merge_shards": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
