@@ -247,6 +247,9 @@ int sann_debug_phase_cycles(sann_batch_t *batch, int32_t enable, double *avg16);
  * before they consume the current one.  *checksum is the same for both modes. */
 int sann_debug_gather_probe(sann_batch_t *batch, int32_t mode, int32_t wgs_per_cu, int32_t reps, double *ms_avg,
                             uint64_t *checksum);
+/* Debug: per-unit arrays of the last run ([nq * n_partitions] each; any may be NULL): distinct tweets accumulated,
+ * candidates emitted, UNIT_* flags, postings scanned. */
+int sann_debug_unit_arrays(sann_batch_t *batch, int32_t *unit_unique, int32_t *cand_cnt, uint32_t *unit_flags, int32_t *unit_T);
 /* Debug: after sann_batch_run + a device sync and BEFORE sann_batch_finish, histogram of why fast
  * units overflowed: [1] too many scanned clusters, [2] too many postings, [3] too many
  * multi-cluster tweets, [4] score outside the fp32 pre-filter range / hash clash, [5] tie group. */

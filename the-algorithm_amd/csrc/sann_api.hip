@@ -1215,6 +1215,18 @@ int sann_debug_gather_probe(sann_batch_t *b, int32_t mode, int32_t wgs_per_cu, i
   return SANN_OK;
 }
 
+int sann_debug_unit_arrays(sann_batch_t *b, int32_t *unit_unique, int32_t *cand_cnt, uint32_t *unit_flags, int32_t *unit_T) {
+  if (!b) return fail(SANN_EINVAL, "batch is NULL");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t n = (size_t)b->n_units * 4;
+  if (unit_unique) HIP_TRY(hipMemcpy(unit_unique, b->unit_unique.p, n, hipMemcpyDeviceToHost));
+  if (cand_cnt) HIP_TRY(hipMemcpy(cand_cnt, b->cand_cnt.p, n, hipMemcpyDeviceToHost));
+  if (unit_flags) HIP_TRY(hipMemcpy(unit_flags, b->unit_flags.p, n, hipMemcpyDeviceToHost));
+  if (unit_T) HIP_TRY(hipMemcpy(unit_T, b->unit_T.p, n, hipMemcpyDeviceToHost));
+  return SANN_OK;
+}
+
 int sann_debug_overflow_reasons(sann_batch_t *b, int32_t *counts8, int32_t *n_inexact) {
   if (!b || !counts8) return fail(SANN_EINVAL, "NULL argument");
   HIP_TRY(hipSetDevice(b->ix->device));

@@ -38,6 +38,8 @@
 // range, an unresolvable tie group) flag UNIT_OVERFLOW and are re-run by unit_general_kernel.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "sann_device.h"
 #include "sann_kernels.h"
 #include "sann_math.h"
@@ -253,34 +255,60 @@ enum {
     if (sink_ == 0x123456789abcdefull) b.unit_thr[2 * (int64_t)unit] = sink_;                                \
     return;                                                                                                  \
   }
-template <int WG, int U, int ABL = 0>
-__global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 8 ? 5 : 3)) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
+// NS = scanned clusters the unit's tables hold (64 when the batch's queries scan at most 64 -- the production N is 50 --
+// else NSCAN_MAX): with the match list moved into the dead Bloom filter's memory the six-slot geometry then needs
+// 20.0 KB of LDS and 64 registers, i.e. EIGHT workgroups per CU (the hardware's 32 waves) instead of six.
+template <int WG, int U, int NS = NSCAN_MAX, int ABL = 0>
+#ifdef SANN_EXP_LB6
+#define SANN_LB6_ 7
+#else
+#define SANN_LB6_ 7
+#endif
+__global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5 : 3)) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
   constexpr int SCAP = FAST_SCAP;
   constexpr int BW = bloom_log2(WG * U);  // log2 of the Bloom filter's 64-bit words
   constexpr int BLOOM_ALLOC = 1 << BW;
   constexpr int HB = 18 + BW;  // hash bits: 3 x 6 bit positions, then the word index
-  constexpr int FBLOOM_WORDS = BW >= 11 ? 128 : 256;  // (the 16 KB Bloom filter leaves room for 128: five workgroups per CU)
+#ifdef SANN_EXP_FB7
+  constexpr int FBLOOM_WORDS = BW >= 11 ? 128 : 256;
   constexpr int FB = BW >= 11 ? 7 : 8;
+#else
+  constexpr int FBLOOM_WORDS = BW >= 11 ? 64 : 256;  // (beside the 16 KB Bloom filter: 64, so that eight workgroups fit a CU)
+  constexpr int FB = BW >= 11 ? 6 : 8;
+#endif
   constexpr int MCAP = (WG * U <= 1024) ? 64 : 128;
   __shared__ unsigned long long s_bloom[BLOOM_ALLOC];
-  __shared__ uint32_t s_begin[NSCAN_MAX];
-  __shared__ uint32_t s_pre[NSCAN_MAX];
+  __shared__ uint32_t s_begin[NS];
+  __shared__ uint32_t s_pre[NS];
   __shared__ uint8_t s_map[WG * U];  // flat posting index -> cluster sequence number
-  __shared__ double s_w[NSCAN_MAX];
-  __shared__ float s_w32[NSCAN_MAX];
-  __shared__ uint32_t s_wkey[NSCAN_MAX];  // cosine forms: the fp32 key of a single-cluster candidate of the cluster (0 = untrusted)
+  __shared__ double s_w[NS];
+  __shared__ float s_w32[NS];
+  __shared__ uint32_t s_wkey[NS];  // cosine forms: the fp32 key of a single-cluster candidate of the cluster (0 = untrusted)
   __shared__ unsigned long long s_fbloom[FBLOOM_WORDS];
-  __shared__ long long s_Mid[MCAP];
-  __shared__ int s_Mseq[MCAP], s_Mrole[MCAP];
-  __shared__ double s_Msc[MCAP], s_Mdot[MCAP], s_Mnsq[MCAP];
-  // The survivor list and the radix histogram are first touched after the duplicate phase, when the Bloom filter is
-  // dead: with a filter of >= 1024 words they live in its memory (barriers at the end of phase 3 lie between).
+  // The survivor list, the radix histogram / lane maxima and the match list of the duplicate phase are first touched
+  // after the Bloom filter is dead (the barrier that ends phase 2 lies between): they live in its memory when it is
+  // large enough.
   constexpr bool ALIAS = BLOOM_ALLOC >= SCAP + 128;
+  constexpr int M_OFF = SCAP + 128;  // in 8-byte words: behind the survivor list and the histogram
+#ifdef SANN_EXP_NO_ALIAS_M
+  constexpr bool ALIAS_M = false;
+#else
+  constexpr bool ALIAS_M = ALIAS && BLOOM_ALLOC >= M_OFF + 5 * MCAP;
+#endif
   __shared__ unsigned long long s_ent_own[ALIAS ? 1 : SCAP];
   __shared__ unsigned s_hist_own[ALIAS ? 1 : 256];
+  __shared__ long long s_Mid_own[ALIAS_M ? 1 : MCAP];
+  __shared__ double s_Msc_own[ALIAS_M ? 1 : MCAP], s_Mdot_own[ALIAS_M ? 1 : MCAP], s_Mnsq_own[ALIAS_M ? 1 : MCAP];
+  __shared__ int s_Mseq_own[ALIAS_M ? 1 : MCAP], s_Mrole_own[ALIAS_M ? 1 : MCAP];
   // survivor list: (cluster sequence number or 0x10000 | match-list entry) << 32 | position of the posting in the index
   unsigned long long *const s_ent = ALIAS ? s_bloom : s_ent_own;
   unsigned *const s_hist = ALIAS ? reinterpret_cast<unsigned *>(s_bloom + SCAP) : s_hist_own;
+  long long *const s_Mid = ALIAS_M ? reinterpret_cast<long long *>(s_bloom + M_OFF) : s_Mid_own;
+  double *const s_Msc = ALIAS_M ? reinterpret_cast<double *>(s_bloom + M_OFF + MCAP) : s_Msc_own;
+  double *const s_Mdot = ALIAS_M ? reinterpret_cast<double *>(s_bloom + M_OFF + 2 * MCAP) : s_Mdot_own;
+  double *const s_Mnsq = ALIAS_M ? reinterpret_cast<double *>(s_bloom + M_OFF + 3 * MCAP) : s_Mnsq_own;
+  int *const s_Mseq = ALIAS_M ? reinterpret_cast<int *>(s_bloom + M_OFF + 4 * MCAP) : s_Mseq_own;
+  int *const s_Mrole = ALIAS_M ? reinterpret_cast<int *>(s_bloom + M_OFF + 4 * MCAP) + MCAP : s_Mrole_own;
   __shared__ int s_ctl[CTL_N];
 
   const int tid = threadIdx.x;
@@ -301,7 +329,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
   for (int i = tid; i < BLOOM_ALLOC; i += WG) s_bloom[i] = 0ull;
   for (int i = tid; i < FBLOOM_WORDS; i += WG) s_fbloom[i] = 0ull;
 
-  const bool overflow_n = h.n_scan > NSCAN_MAX;  // uniform
+  const bool overflow_n = h.n_scan > NS;  // uniform
   // ---- 1. descriptors ----------------------------------------------------------------------
   // The unit's posting count T and its descriptor row are loaded together: nothing below branches on T before
   // the descriptor loads are issued (a branch on T first cost a second, serial trip to memory).
@@ -335,8 +363,10 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
   asm volatile("" : "+v"(Tv));
   const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tv);
   bool overflow = overflow_n;
-  int why = overflow ? 1 : 0;  // overflow reason (kept in unit_thr[2u+1] for diagnostics)
-  if (!overflow && T > (uint32_t)(WG * U)) { overflow = true; why = 2; }
+  // overflow reason, for diagnostics (unit_thr[2u+1]): 1 scanned clusters, 2 postings, 3 match list, 4 key range.  Derived
+  // at the exit from facts that are uniform anyway, not carried in a register (it was the last value hipcc spilled).
+  if (!overflow && T > (uint32_t)(WG * U)) overflow = true;
+  const bool overflow_T = overflow && !overflow_n;
   __syncthreads();
   STAMP(1);  // descriptors + map done
 
@@ -470,11 +500,13 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
     const int nm = s_ctl[CTL_NM];
     if (nm > MCAP) {
       overflow = true;
-      why = 3;
+      if (tid == 0) s_ctl[CTL_BAD] = 8;  // (diagnostics: the match list overflowed)
     } else {
-      if (nm > 64 || nm <= 12) {
-        // tiny match list (a few Bloom false positives: the common case on a large corpus) or a very
-        // large one (duplicate-heavy corpus): one thread per entry, ids compared inside M
+      {
+        // one thread per match-list entry, ids compared inside M (a handful of entries on a large corpus -- mostly
+        // Bloom false positives -- up to MCAP on a duplicate-heavy one).  (A wave-sorted variant for 13..64 entries
+        // was dropped: its eight-wide register groups were what pushed hipcc into spilling, and ROCm 7.2 places
+        // VGPR spill stores in front of the exec-mask restore of a join block -- lanes then reload garbage.)
         for (int m = tid; m < nm; m += WG) {
           const long long my = s_Mid[m];
           const int myseq = s_Mseq[m];
@@ -509,87 +541,6 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
           }
           s_Mrole[m] = role;
         }
-      } else if (tid < 64) {
-        // One wave settles M.  Sort the 32-bit keys (hash24(id) << 8 | m) so that postings of the
-        // same tweet become adjacent, then every run leader handles its (tiny) group.
-        const int lane = tid;
-        uint32_t key = 0xffffffffu;
-        if (lane < nm) {
-          const long long idm = s_Mid[lane];
-          // independent of table_hash: M's members were selected for agreeing on table_hash bits
-          key = ((uint32_t)(mix64((uint64_t)idm) >> 40) << 8) | (uint32_t)lane;
-        }
-#pragma unroll
-        for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-          for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t other = __shfl_xor(key, j, 64);
-            const bool up = (lane & k) == 0, lower = (lane & j) == 0;
-            key = (lower == up) ? (key < other ? key : other) : (key > other ? key : other);
-          }
-        }
-        const uint32_t prev = __shfl_up(key, 1, 64);
-        const bool valid = key != 0xffffffffu;
-        const bool leader = valid && (lane == 0 || (prev >> 8) != (key >> 8));
-        const int m0 = (int)(key & 0xffu);
-        // leaders walk their run (runs are 1-3 long; > 8 or a hash collision -> general path)
-        int mem[8];
-        int cnt = leader ? 1 : 0;
-        mem[0] = m0;
-        bool clash = false;
-#pragma unroll
-        for (int rr = 1; rr < 8; rr++) {
-          const uint32_t nxt = __shfl_down(key, rr, 64);
-          const bool cont = leader && cnt == rr && lane + rr < 64 && nxt != 0xffffffffu && (nxt >> 8) == (key >> 8);
-          mem[rr] = cont ? (int)(nxt & 0xffu) : 0;
-          cnt += cont ? 1 : 0;
-        }
-        {
-          const uint32_t nxt8 = __shfl_down(key, 8, 64);
-          if (leader && cnt == 8 && lane + 8 < 64 && nxt8 != 0xffffffffu && (nxt8 >> 8) == (key >> 8)) clash = true;
-        }
-        if (leader && cnt >= 2) {
-          const long long my = s_Mid[m0];
-          int sq[8];
-          double sv[8];
-#pragma unroll
-          for (int rr = 0; rr < 8; rr++) {
-            sq[rr] = 0x7fffffff;
-            sv[rr] = 0.0;
-            if (rr < cnt) {
-              if (s_Mid[mem[rr]] != my) clash = true;  // 24-bit hash collision between different tweets
-              sq[rr] = s_Mseq[mem[rr]];
-              sv[rr] = s_Msc[mem[rr]];
-            }
-          }
-          // ordered accumulation: repeatedly take the smallest remaining cluster sequence
-          double dot = 0.0, nsq = 0.0;
-          int rep = 0;
-          int last = -1;
-          for (int t2 = 0; t2 < cnt; t2++) {
-            int best = 0x7fffffff, bi = 0;
-#pragma unroll
-            for (int rr = 0; rr < 8; rr++)
-              if (sq[rr] > last && sq[rr] < best) { best = sq[rr]; bi = rr; }
-            double bs = 0.0;
-#pragma unroll
-            for (int rr = 0; rr < 8; rr++) bs = (rr == bi) ? sv[rr] : bs;
-            if (t2 == 0) rep = bi;
-            dot = dot + bs * s_w[best];  // :92-94
-            nsq = nsq + bs * bs;         // :95-96
-            last = best;
-          }
-#pragma unroll
-          for (int rr = 0; rr < 8; rr++)
-            if (rr < cnt) {
-              const int mm = mem[rr];
-              s_Mrole[mm] = (rr == rep) ? 1 : 2;  // 1 = carries the group's sums, 2 = folded away
-              if (rr == rep) { s_Mdot[mm] = dot; s_Mnsq[mm] = nsq; }
-            }
-        } else if (leader) {
-          s_Mrole[m0] = 0;  // on its own (Bloom false positive)
-        }
-        if (__ballot(clash) != 0ull && lane == 0) s_ctl[CTL_BAD] = 2;
       }
       __syncthreads();
       int folded = 0;
@@ -629,7 +580,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const bool lv = seq[u] >= 0;
-        const uint32_t wk = s_wkey[lv ? (seq[u] & (NSCAN_MAX - 1)) : 0];
+        const uint32_t wk = s_wkey[lv ? (seq[u] & (NS - 1)) : 0];
         // the shortcut is only trusted for ordinary positive magnitudes (s32^2 within the fp32 range, w / l2norm too)
         bad = bad || (lv && !(seq[u] & 0x10000) && !(s32[u] > 1e-15f && s32[u] < 1e15f && wk != 0u));
         k32[u] = lv ? wk : 0u;
@@ -640,7 +591,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const bool lv = seq[u] >= 0;
-        const float a = s32[u] * s_w32[lv ? (seq[u] & (NSCAN_MAX - 1)) : 0];
+        const float a = s32[u] * s_w32[lv ? (seq[u] & (NS - 1)) : 0];
         bad = bad || (lv && !(seq[u] & 0x10000) && !(a > 1e-30f && a < 1e30f));
         k32[u] = lv ? (__float_as_uint(a) | 0x80000000u) : 0u;
       }
@@ -660,7 +611,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
             const double sd = ix.postings[s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c])].score;
             nsq64 = sd * sd;
           }
-          a = approx_score(3, sv * s_w32[seq[u] & (NSCAN_MAX - 1)], sv * sv, nsq64, 0.f, invln, &forced);
+          a = approx_score(3, sv * s_w32[seq[u] & (NS - 1)], sv * sv, nsq64, 0.f, invln, &forced);
         }
         bad = bad || (lv && !(seq[u] & 0x10000) && !forced && !(a > 1e-30f && a < 1e30f && sv > 1e-15f && sv < 1e15f));
         k32[u] = lv ? (forced ? FORCED_KEY : (__float_as_uint(a) | 0x80000000u)) : 0u;
@@ -709,7 +660,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
     s_lm[tid] = wave_sort_desc_u32(m);
   }
   __syncthreads();
-  if (s_ctl[CTL_BAD] && !overflow) { overflow = true; why = (s_ctl[CTL_BAD] & 2) ? 6 : 4; }
+  if (s_ctl[CTL_BAD] && !overflow) overflow = true;
 
   if (overflow) {
     if (tid == 0) {
@@ -717,7 +668,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
       b.unit_unique[unit] = 0;
       b.unit_flags[unit] = UNIT_OVERFLOW;
       b.unit_thr[2 * (int64_t)unit] = 0;
-      b.unit_thr[2 * (int64_t)unit + 1] = (unsigned long long)why;
+      b.unit_thr[2 * (int64_t)unit + 1] = overflow_n ? 1ull : overflow_T ? 2ull : (s_ctl[CTL_BAD] & 8) ? 3ull : 4ull;
       const int o = atomicAdd(&b.status[0], 1);
       b.overflow_units[o] = unit;
     }
@@ -755,7 +706,11 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 4 ? 8 : U <= 6 ? 6 : U <= 
       }
       rank += pos;
     }
-    if (rank == kl - 1) s_ctl[CTL_SEL_D] = (int)m;  // ranks are a permutation: exactly one thread (none when kl > WG: tau = 0)
+    // ranks are a permutation: exactly one thread writes (none when kl > WG: tau stays 0).  The cut goes 256 fp32 ulps
+    // (>= 3 EPS) BELOW that value: everything below the cut is then bounded by theta = tau (1 + 2 EPS) <= m (1 - EPS),
+    // which the candidates that tie with m (in the near-tie regime: the whole cluster group the cut falls into) still
+    // reach with their exact scores -- a cut exactly at m emitted none of them, and the merge could not prove the query.
+    if (rank == kl - 1) s_ctl[CTL_SEL_D] = (int)(m > 0x80000100u ? m - 256u : m);
     __syncthreads();
     tau = (uint32_t)s_ctl[CTL_SEL_D];
   }
@@ -925,7 +880,11 @@ template <int WG, int U>
 static hipError_t launch_one(const IndexView &ix, const BatchView &b, const FastParams &fp, hipStream_t stream) {
   const int nq8 = (b.nq + 7) / 8 * 8;
   const int n_blocks = nq8 * ix.P;
-  hipLaunchKernelGGL((unit_fast_kernel<WG, U>), dim3(n_blocks), dim3(WG), 0, stream, ix, b, fp.k_local, n_blocks);
+  static const int pad_lds = getenv("SANN_EXP_PAD_LDS") ? atoi(getenv("SANN_EXP_PAD_LDS")) : 0;  // experiment: caps occupancy
+  if (fp.max_n_scan <= 64)
+    hipLaunchKernelGGL((unit_fast_kernel<WG, U, 64>), dim3(n_blocks), dim3(WG), (size_t)pad_lds, stream, ix, b, fp.k_local, n_blocks);
+  else
+    hipLaunchKernelGGL((unit_fast_kernel<WG, U, NSCAN_MAX>), dim3(n_blocks), dim3(WG), 0, stream, ix, b, fp.k_local, n_blocks);
   return hipGetLastError();
 }
 
@@ -1033,12 +992,12 @@ hipError_t launch_unit_ablation(const IndexView &ix, const BatchView &b, const F
   const int n_blocks = nq8 * ix.P;
   if (fp.unit_capacity != 1536) return hipErrorInvalidValue;
   switch (abl) {
-    case 0: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 0>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
-    case 1: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 1>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
-    case 2: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 2>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
-    case 3: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 3>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
-    case 4: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 4>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
-    case 5: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 5>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 0: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 0>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 1: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 1>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 2: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 2>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 3: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 3>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 4: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 4>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 5: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 5>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

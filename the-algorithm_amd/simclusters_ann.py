@@ -22,7 +22,7 @@ from typing import Callable, Dict, Iterable, List, Mapping, Optional, Sequence, 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsimclusters_amd.so")
+LIB_PATH = os.environ.get("SANN_LIB_PATH") or os.path.join(_HERE, "libsimclusters_amd.so")  # (override: A/B builds)
 
 
 class ScoringAlgorithm(enum.IntEnum):
@@ -165,6 +165,7 @@ _PROTOS = {
     "sann_device_synchronize": (C.c_int, [C.c_int32]),
     "sann_debug_overflow_reasons": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sann_debug_gather_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "sann_debug_unit_arrays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sann_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "sann_batch_destroy": (C.c_int, [C.c_void_p]),
     "sann_get_tweet_candidates": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
