@@ -260,9 +260,9 @@ enum {
 // 20.0 KB of LDS and 64 registers, i.e. EIGHT workgroups per CU (the hardware's 32 waves) instead of six.
 template <int WG, int U, int NS = NSCAN_MAX, int ABL = 0>
 #ifdef SANN_EXP_LB6
-#define SANN_LB6_ 7
+#define SANN_LB6_ 8
 #else
-#define SANN_LB6_ 7
+#define SANN_LB6_ 8
 #endif
 __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5 : 3)) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
   constexpr int SCAP = FAST_SCAP;
@@ -378,18 +378,19 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
   // in scratch memory, re-reading them in every later phase.
   float s32[U];   // posting score, fp32
   int seq[U];     // cluster sequence number; bit 16 = group representative (low bits: match-list entry); < 0 = no candidate here
-  uint32_t hsh[U];  // table_hash of the tweet id (Bloom word and bits; dead after the duplicate phase)
   int live = 0;
 #pragma unroll
   for (int u = 0; u < U; u++) {
     seq[u] = -1;
     s32[u] = 0.f;
-    hsh[u] = 0u;
   }
   {
     // an overflowed unit gathers nothing: with Tg = 0 every slot below is skipped, and no separate control path
     // has to be merged with the loaded registers (the merge made hipcc wait for the first slot's load at once)
     const uint32_t Tg = overflow ? 0u : T;
+    uint32_t hsh[U];  // table_hash of the tweet id (Bloom word and bits): lives only as long as this block
+#pragma unroll
+    for (int u = 0; u < U; u++) hsh[u] = 0u;
     // The loads are written as inline asm and waited for by hand.  Left to hipcc, the six 16-byte loads of a thread
     // were given OVERLAPPING destination registers (the id half of one under the score half of the next) with an
     // `s_waitcnt vmcnt(0)` + register copy behind every one of them: six serial trips to memory instead of one.
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
     unsigned long long x_ = 0;
     if constexpr (ABL == 1) {
 #pragma unroll
-      for (int u = 0; u < U; u++) x_ ^= (unsigned long long)__float_as_uint(s32[u]) ^ ((unsigned long long)hsh[u] << 32) ^ (unsigned)seq[u];
+      for (int u = 0; u < U; u++) x_ ^= (unsigned long long)__float_as_uint(s32[u]) ^ (unsigned)seq[u];
     }
     ABLATE(1, x_ + (unsigned)s_ctl[CTL_NFLAG] + (unsigned)s_ctl[CTL_LIVE]);
   }
@@ -476,19 +477,28 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
   // earlier postings of the same tweet, and a few hash collisions) joins the match list M; one
   // thread per M entry then settles its group by comparing ids inside M only.
   if (!overflow && s_ctl[CTL_NFLAG] != 0) {
+    // a flagged unit (one in five at the benchmark's shape, mostly by Bloom false positives) fetches its postings
+    // again -- from L2 -- rather than every unit carrying 4 more bytes per posting through the whole kernel
+    Posting pagain[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int c = seq[u] >= 0 ? seq[u] : 0;
+      const uint32_t j = (uint32_t)(u * WG + tid);
+      pagain[u] = seq[u] >= 0 ? ix.postings[s_begin[c] + (j - s_pre[c])] : Posting{0, 0.0};
+    }
     int mi[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       mi[u] = -1;
       if (seq[u] >= 0) {
-        const uint32_t hv = hsh[u];
+        const int c = seq[u];
+        const Posting pm = pagain[u];
+        const uint32_t hv = table_hash(pm.id, HB);
         const unsigned long long bits = (1ull << (hv & 63)) | (1ull << ((hv >> 6) & 63)) | (1ull << ((hv >> 12) & 63));
         if ((s_fbloom[hv >> (HB - FB)] & bits) == bits) {
           const int m = atomicAdd(&s_ctl[CTL_NM], 1);
           mi[u] = m;
           if (m < MCAP) {
-            const int c = seq[u];
-            const Posting pm = ix.postings[s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c])];  // the posting itself, again
             s_Mid[m] = pm.id;
             s_Mseq[m] = c;
             s_Msc[m] = pm.score;
@@ -634,7 +644,8 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
 #endif
     if (__ballot(bad) != 0ull && (tid & 63) == 0) atomicOr(&s_ctl[CTL_BAD], 1);
   }
-  const int n_live = s_ctl[CTL_LIVE];
+  // (the live count is read from LDS where it is used, three times in all, rather than held in a register across
+  // the whole back half: at 64 registers hipcc spilled it)
   int kl;
   {
     const float share = (float)h.k / (float)ix.P;
@@ -652,7 +663,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
   // LDS atomics (the radix histogram this replaces spent 25 % of the kernel serialising atomics on the few distinct
   // keys a near-tie batch has).  A cut that keeps more than SCAP falls back to that histogram (5c).
   uint32_t *const s_lm = s_hist;  // [WG], in the dead Bloom filter's memory (or s_hist_own, which is WG <= 256 words)
-  const bool select = n_live > keep_all && !overflow;  // uniform
+  const bool select = s_ctl[CTL_LIVE] > keep_all && !overflow;  // uniform
   if (select) {
     uint32_t m = 0u;
 #pragma unroll
@@ -724,113 +735,51 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
     ABLATE(4, x_ + tau);
   }
   // ---- 5b. compact the survivors with their exact (dot, nsq): one LDS atomic per wave ------------------------------
-  for (int attempt = 0;; attempt++) {
+  {
     int total = 0;
-    unsigned long long msk[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      msk[u] = __ballot(k32[u] != 0u && k32[u] >= tau);
-      total += __popcll(msk[u]);
-    }
+    for (int u = 0; u < U; u++) total += __popcll(__ballot(k32[u] != 0u && k32[u] >= tau));
     int base = 0;
     if ((tid & 63) == 0 && total) base = atomicAdd(&s_ctl[CTL_NSURV], total);
     base = __shfl(base, 0, 64);
     const unsigned long long below = (1ull << (tid & 63)) - 1ull;
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if (k32[u] != 0u && k32[u] >= tau) {
-        const int o = base + __popcll(msk[u] & below);
+      const bool sv = k32[u] != 0u && k32[u] >= tau;
+      const unsigned long long m = __ballot(sv);  // (recomputed rather than kept: six live masks cost 12 SGPRs)
+      if (sv) {
+        const int o = base + __popcll(m & below);
         if (o < SCAP) {
           const int c = seq[u];
           const uint32_t pos = (c & 0x10000) ? 0u : s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c]);
           s_ent[o] = ((unsigned long long)(uint32_t)c << 32) | pos;
         }
       }
-      base += __popcll(msk[u]);
+      base += __popcll(m);
     }
-    __syncthreads();
-    if (s_ctl[CTL_NSURV] <= SCAP || attempt == 1) break;  // uniform
-    // ---- 5c. (rare) the cut kept too many: MSB-first radix histogram over the 32-bit keys, started at the highest
-    // bit in which the unit's keys differ, for a cut with between kl and SCAP candidates above it
-    {
-      uint32_t kmin = 0xffffffffu, kmax = 0u;
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        kmin = k32[u] != 0u && k32[u] < kmin ? k32[u] : kmin;
-        kmax = k32[u] > kmax ? k32[u] : kmax;
-      }
-      const uint32_t wmin = wave_min_u32(kmin), wmax = wave_max_u32(kmax);
-      for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
-      if ((tid & 63) == 0) {
-        atomicMin((unsigned *)&s_ctl[CTL_KMIN], wmin);
-        atomicMax((unsigned *)&s_ctl[CTL_KMAX], wmax);
-      }
-      if (tid == 0) s_ctl[CTL_NSURV] = 0;
+  }
+  __syncthreads();
+  // A cut that keeps more than the survivor list holds (many candidates sharing threads with larger ones, or a tie
+  // group of more than ~100 identical keys -- which no finer cut could split either) sends the unit to the general
+  // path.  (Round 1 re-cut such units with a radix histogram over all keys; it fired too rarely to earn its registers.)
+  if (s_ctl[CTL_NSURV] > SCAP) {
+    if (tid == 0) {
+      b.cand_cnt[unit] = 0;
+      b.unit_unique[unit] = 0;
+      b.unit_flags[unit] = UNIT_OVERFLOW;
+      b.unit_thr[2 * (int64_t)unit] = 0;
+      b.unit_thr[2 * (int64_t)unit + 1] = 5ull;
+      const int o = atomicAdd(&b.status[0], 1);
+      b.overflow_units[o] = unit;
     }
-    __syncthreads();
-    bool give_up = false;
-    {
-      const uint32_t gmin = (uint32_t)s_ctl[CTL_KMIN], gmax = (uint32_t)s_ctl[CTL_KMAX];
-      const uint32_t diff = gmin ^ gmax;
-      if (diff == 0) {
-        give_up = true;  // every approximate score identical and too many of them
-      } else {
-        const int hbit = 31 - __clz((int)diff);
-        int shift = hbit - 7 < 0 ? 0 : hbit - 7;
-        int width = hbit - shift + 1;
-        uint32_t prefix = (hbit == 31) ? 0u : (gmax >> (hbit + 1)) << (hbit + 1);
-        int need = kl, budget = SCAP;
-        for (bool first = true;; first = false) {
-          if (!first) {
-            for (int i = tid; i < 256; i += WG) s_hist[i] = 0;
-            __syncthreads();
-          }
-          const uint32_t hi_mask = (shift + width >= 32) ? 0u : (~0u << (shift + width));
-#pragma unroll
-          for (int u = 0; u < U; u++) {
-            const uint32_t k = k32[u];
-            if (k != 0u && (k & hi_mask) == (prefix & hi_mask)) atomicAdd(&s_hist[(k >> shift) & ((1u << width) - 1)], 1u);
-          }
-          __syncthreads();
-          if (tid < 64) wave_find_digit(s_hist, need, &s_ctl[CTL_SEL_D]);  // writes D, A, B
-          __syncthreads();
-          const int d = s_ctl[CTL_SEL_D], A = s_ctl[CTL_SEL_A], B = s_ctl[CTL_SEL_B];
-          prefix |= (uint32_t)d << shift;
-          bool stop = false;
-          if (A + B <= budget) stop = true;
-          else if (shift == 0) { give_up = true; stop = true; }  // too many identical approximations
-          else {
-            need -= A;
-            budget -= A;
-            const int ns2 = shift - 8 < 0 ? 0 : shift - 8;
-            width = shift - ns2;
-            shift = ns2;
-          }
-          if (stop) break;  // uniform; nothing below reuses the histogram or these control words
-          __syncthreads();
-        }
-        tau = prefix;
-      }
-    }
-    if (give_up) {
-      if (tid == 0) {
-        b.cand_cnt[unit] = 0;
-        b.unit_unique[unit] = 0;
-        b.unit_flags[unit] = UNIT_OVERFLOW;
-        b.unit_thr[2 * (int64_t)unit] = 0;
-        b.unit_thr[2 * (int64_t)unit + 1] = 5ull;
-        const int o = atomicAdd(&b.status[0], 1);
-        b.overflow_units[o] = unit;
-      }
-      return;
-    }
+    return;
   }
   const int ns = s_ctl[CTL_NSURV] < SCAP ? s_ctl[CTL_NSURV] : SCAP;
   // theta: every candidate below the cut has approx < tau, hence exact < tau * (1 + 2 EPS)
   unsigned long long theta_key = 0ull;
   // ... unless every live candidate survived the cut (tau can be non-zero and still below all of them when the
   // need-th key sits in the lowest occupied digit): then nothing is withheld and nothing may be dropped below.
-  if (tau != 0u && s_ctl[CTL_NSURV] < n_live) {
+  if (tau != 0u && s_ctl[CTL_NSURV] < s_ctl[CTL_LIVE]) {
     double tau_val = (double)__uint_as_float(tau & 0x7fffffffu);
     tau_val = tau_val < 1e30 ? tau_val : 1e30;  // a cut inside the forced (+inf) band: the others are still < 1e30
     theta_key = score_key(tau_val * (1.0 + 2.0 * (double)APPROX_EPS));
@@ -840,7 +789,9 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
   ABLATE(5, (unsigned long long)ns + theta_key + s_ent[tid % SCAP]);
   // ---- 6. the survivors' postings again (one parallel trip, mostly to L2), exact fp64 scores, emit ------------------
   const int64_t obase = (int64_t)unit * b.cap;
-  for (int i = tid; i < ns; i += WG) {
+  int i_first = tid;
+  asm volatile("" : "+v"(i_first));  // (a fresh index: hipcc otherwise keeps tid * 8 from the first lines alive, in scratch)
+  for (int i = i_first; i < ns; i += WG) {
     const unsigned long long e = s_ent[i];
     const int c = (int)(e >> 32);
     long long idv;
@@ -865,6 +816,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
   }
   __syncthreads();
   if (tid == 0) {
+    const int n_live = s_ctl[CTL_LIVE];
     const bool withheld = n_live > ns;  // candidates below the cut were not examined exactly
     b.cand_cnt[unit] = s_ctl[CTL_CNT];
     b.unit_unique[unit] = n_live;
