@@ -242,7 +242,7 @@ __device__ inline uint32_t wave_sort_desc_u32(uint32_t v) {
 constexpr int bloom_log2(int capacity) { return capacity <= 512 ? 8 : capacity <= 1024 ? 9 : 11; }
 
 enum {
-  CTL_NFLAG = 0, CTL_NM, CTL_LIVE, CTL_NSURV, CTL_CNT, CTL_SEL_D, CTL_SEL_A, CTL_SEL_B, CTL_BAD, CTL_KMIN, CTL_KMAX,
+  CTL_NFLAG = 0, CTL_NM, CTL_LIVE, CTL_NSURV, CTL_CNT, CTL_SEL_D, CTL_SEL_A, CTL_SEL_B, CTL_BAD, CTL_KMIN, CTL_KMAX, CTL_PRE,
   CTL_N
 };
 
@@ -370,6 +370,22 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
   __syncthreads();
   STAMP(1);  // descriptors + map done
 
+  // entries a unit must offer before it may withhold the rest (its share of k, six sigma, and a few), and the size
+  // up to which it simply offers everything
+  int kl;
+  {
+    const float share = (float)h.k / (float)ix.P;
+    kl = (int)(share + 6.0f * sqrtf(share) + 8.0f);
+    if (kl < k_local_floor) kl = k_local_floor;
+    if (kl > h.k) kl = h.k;
+    if (kl > SCAP - 32) kl = SCAP - 32;
+  }
+  const int keep_all = SCAP < kl + kl / 2 + 16 ? SCAP : kl + kl / 2 + 16;
+  // Cosine forms: a single-cluster candidate's key is a constant of its cluster, so WHERE to cut can be decided from
+  // the descriptors alone -- clusters by key, postings counted until kl are covered -- before a single posting has
+  // arrived: wave 0 does that in the shadow of the posting loads (5a'), and the data-dependent cut (5a) is skipped.
+  const bool pre_cut = (h.alg == 2 || h.alg == 4) && h.n_scan <= 64 && !overflow;  // uniform
+
   // ---- 2. gather ---------------------------------------------------------------------------------------
   // A posting is looked at ONCE: window / source filters on its id, three Bloom bits from a hash of its id, and its
   // score rounded to fp32 for the pre-filter.  What stays in registers per posting is 12 bytes -- (s32, cluster, hash)
@@ -410,6 +426,37 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
         asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[u]) : "v"(src) : "memory");
       }
     STAMP(2);  // posting loads issued
+    if (pre_cut && tid < 64) {
+      // ---- 5a'. cluster-level cut (wave 0, while the loads are in flight) -----------------------------------------
+      // lane c = cluster c: its key with the low 8 bits replaced by c (keys 256 ulps apart tie; the cut is taken 256
+      // ulps low anyway), sorted descending; postings per cluster from the descriptors' prefix; the first cluster at
+      // which the running count reaches kl gives the cut.
+      const int lane = tid;
+      uint32_t pk = 0u;
+      if (lane < h.n_scan) {
+        const uint32_t kc = s_wkey[lane];
+        pk = kc ? ((kc & ~0xffu) | (uint32_t)lane) : 0u;
+      }
+      pk = wave_sort_desc_u32(pk);
+      const int c = (int)(pk & 0xffu);
+      int cum = 0;
+      if (pk) {
+        const uint32_t lo = s_pre[c], hi = (c + 1 < h.n_scan) ? s_pre[c + 1] : Tg;
+        cum = (int)((hi < Tg ? hi : Tg) - (lo < Tg ? lo : Tg));
+      }
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(cum, off, 64);
+        cum += lane >= off ? t : 0;
+      }
+      const unsigned long long ok = __ballot(pk != 0u && cum >= kl);
+      uint32_t tp = 0u;  // 0 = the unit's postings do not even add up to kl: keep everything
+      if (ok != 0ull) {
+        const uint32_t kc = s_wkey[__shfl(c, __ffsll((long long)ok) - 1, 64)];
+        tp = kc > 0x80000100u ? kc - 256u : kc;  // (256 ulps low: see 5a)
+      }
+      if (lane == 0) s_ctl[CTL_PRE] = (int)tp;
+    }
     if constexpr (U == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]) : : "memory");
     else if constexpr (U == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) : : "memory");
     else if constexpr (U == 6)
@@ -644,35 +691,113 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
 #endif
     if (__ballot(bad) != 0ull && (tid & 63) == 0) atomicOr(&s_ctl[CTL_BAD], 1);
   }
-  // (the live count is read from LDS where it is used, three times in all, rather than held in a register across
-  // the whole back half: at 64 registers hipcc spilled it)
-  int kl;
-  {
-    const float share = (float)h.k / (float)ix.P;
-    kl = (int)(share + 6.0f * sqrtf(share) + 8.0f);
-    if (kl < k_local_floor) kl = k_local_floor;
-    if (kl > h.k) kl = h.k;
-    if (kl > SCAP - 32) kl = SCAP - 32;
-  }
-  const int keep_all = SCAP < kl + kl / 2 + 16 ? SCAP : kl + kl / 2 + 16;
   // ---- 5a. the cut: the kl-th largest LANE MAXIMUM ---------------------------------------------------------------
   // kl distinct candidates reach the kl-th largest of the 256 per-thread maxima, so cutting there keeps at least kl;
   // the few candidates that share a thread with a larger one come on top (about U * kl^2 / n_live: 48 in all at the
-  // benchmark's shape), far below the SCAP the survivor list holds.  Each wave sorts its 64 maxima with shuffles, the
+  // benchmark's shape), far below the SCAP the survivor list holds.  Each wave sorts its 64 maxima in registers, the
   // four sorted runs meet in LDS, and every thread ranks its own value by three 6-step searches: two barriers, no
   // LDS atomics (the radix histogram this replaces spent 25 % of the kernel serialising atomics on the few distinct
-  // keys a near-tie batch has).  A cut that keeps more than SCAP falls back to that histogram (5c).
+  // keys a near-tie batch has).  The cut goes 256 fp32 ulps (>= 3 EPS) BELOW the value found: everything below the
+  // cut is then bounded by theta = tau (1 + 2 EPS) <= m (1 - EPS), which the candidates that tie with m (in the
+  // near-tie regime: the whole cluster group the cut falls into) still reach with their exact scores -- a cut exactly
+  // at m emitted none of them, and the merge could not prove the query.
+  // Cosine forms take the cluster-level cut of 5a' instead and come here only if it kept too few (window / source
+  // filters thinned the clusters it counted on).
   uint32_t *const s_lm = s_hist;  // [WG], in the dead Bloom filter's memory (or s_hist_own, which is WG <= 256 words)
-  const bool select = s_ctl[CTL_LIVE] > keep_all && !overflow;  // uniform
-  if (select) {
-    uint32_t m = 0u;
+  uint32_t tau = 0;  // survivors: k32 >= tau
+  bool cut_by_data = !pre_cut;  // uniform
+  if (pre_cut && s_ctl[CTL_LIVE] > keep_all) tau = (uint32_t)s_ctl[CTL_PRE];
+  for (;;) {
+    if (cut_by_data) {
+      const bool select = s_ctl[CTL_LIVE] > keep_all && !overflow;  // uniform
+      if (select) {
+        uint32_t m = 0u;
 #pragma unroll
-    for (int u = 0; u < U; u++) m = k32[u] > m ? k32[u] : m;
-    s_lm[tid] = wave_sort_desc_u32(m);
+        for (int u = 0; u < U; u++) m = k32[u] > m ? k32[u] : m;
+        s_lm[tid] = wave_sort_desc_u32(m);
+      }
+      __syncthreads();
+      STAMP(5);  // approximate keys, lane maxima sorted
+      {
+        unsigned long long x_ = 0;
+        if constexpr (ABL == 3) {
+#pragma unroll
+          for (int u = 0; u < U; u++) x_ ^= (unsigned long long)__float_as_uint(s32[u]) ^ (unsigned)seq[u] ^ k32[u];
+        }
+        ABLATE(3, x_ + s_lm[tid]);
+      }
+      tau = 0u;
+      if (select) {
+        const int lane = tid & 63, wv = tid >> 6;
+        const uint32_t m = s_lm[tid];
+        int rank = lane;  // position in the total order (value desc, wave asc, lane asc)
+#pragma unroll
+        for (int w2 = 0; w2 < WG / 64; w2++) {
+          if (w2 == wv) continue;
+          const uint32_t *L = s_lm + w2 * 64;
+          int pos = 0;  // entries of wave w2's descending run that come before mine
+#pragma unroll
+          for (int step = 32; step >= 1; step >>= 1) {
+            const uint32_t v = L[pos + step - 1];
+            const bool before = v > m || (v == m && w2 < wv);
+            pos += before ? step : 0;
+          }
+          {  // 64 entries = 63 reachable by the steps above, plus the last one
+            const uint32_t v = L[63];
+            pos += (pos == 63 && (v > m || (v == m && w2 < wv))) ? 1 : 0;
+          }
+          rank += pos;
+        }
+        // ranks are a permutation: exactly one thread writes (none when kl > WG: tau stays 0)
+        if (rank == kl - 1) s_ctl[CTL_SEL_D] = (int)(m > 0x80000100u ? m - 256u : m);
+        __syncthreads();
+        tau = (uint32_t)s_ctl[CTL_SEL_D];
+      }
+    }
+    STAMP(6);  // threshold found
+    {
+      unsigned long long x_ = 0;
+      if constexpr (ABL == 4) {
+#pragma unroll
+        for (int u = 0; u < U; u++) x_ ^= (unsigned long long)__float_as_uint(s32[u]) ^ (unsigned)seq[u] ^ k32[u];
+      }
+      ABLATE(4, x_ + tau);
+    }
+    // ---- 5b. compact the survivors: one LDS atomic per wave --------------------------------------------------------
+    {
+      int total = 0;
+#pragma unroll
+      for (int u = 0; u < U; u++) total += __popcll(__ballot(k32[u] != 0u && k32[u] >= tau));
+      int base = 0;
+      if ((tid & 63) == 0 && total) base = atomicAdd(&s_ctl[CTL_NSURV], total);
+      base = __shfl(base, 0, 64);
+      const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const bool sv = k32[u] != 0u && k32[u] >= tau;
+        const unsigned long long m = __ballot(sv);  // (recomputed rather than kept: six live masks cost 12 SGPRs)
+        if (sv) {
+          const int o = base + __popcll(m & below);
+          if (o < SCAP) {
+            const int c = seq[u];
+            const uint32_t pos = (c & 0x10000) ? 0u : s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c]);
+            s_ent[o] = ((unsigned long long)(uint32_t)c << 32) | pos;
+          }
+        }
+        base += __popcll(m);
+      }
+    }
+    __syncthreads();
+    // the cluster-level cut counted postings the filters then removed: cut by the data after all
+    if (!cut_by_data && tau != 0u && s_ctl[CTL_NSURV] < kl && s_ctl[CTL_NSURV] < s_ctl[CTL_LIVE] && !s_ctl[CTL_BAD] && !overflow) {
+      __syncthreads();  // (everyone has read the counters)
+      if (tid == 0) s_ctl[CTL_NSURV] = 0;
+      cut_by_data = true;
+      continue;  // (the barrier after the lane maxima orders the reset before the next compaction)
+    }
+    break;
   }
-  __syncthreads();
   if (s_ctl[CTL_BAD] && !overflow) overflow = true;
-
   if (overflow) {
     if (tid == 0) {
       b.cand_cnt[unit] = 0;
@@ -685,80 +810,6 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
     }
     return;
   }
-
-  STAMP(5);  // approximate keys, lane maxima sorted
-  {
-    unsigned long long x_ = 0;
-    if constexpr (ABL == 3) {
-#pragma unroll
-      for (int u = 0; u < U; u++) x_ ^= (unsigned long long)__float_as_uint(s32[u]) ^ (unsigned)seq[u] ^ k32[u];
-    }
-    ABLATE(3, x_ + s_lm[tid]);
-  }
-  uint32_t tau = 0;  // survivors: k32 >= tau
-  if (select) {
-    const int lane = tid & 63, wv = tid >> 6;
-    const uint32_t m = s_lm[tid];
-    int rank = lane;  // position in the total order (value desc, wave asc, lane asc)
-#pragma unroll
-    for (int w2 = 0; w2 < WG / 64; w2++) {
-      if (w2 == wv) continue;
-      const uint32_t *L = s_lm + w2 * 64;
-      int pos = 0;  // entries of wave w2's descending run that come before mine
-#pragma unroll
-      for (int step = 32; step >= 1; step >>= 1) {
-        const uint32_t v = L[pos + step - 1];
-        const bool before = v > m || (v == m && w2 < wv);
-        pos += before ? step : 0;
-      }
-      {  // 64 entries = 63 reachable by the steps above, plus the last one
-        const uint32_t v = L[63];
-        pos += (pos == 63 && (v > m || (v == m && w2 < wv))) ? 1 : 0;
-      }
-      rank += pos;
-    }
-    // ranks are a permutation: exactly one thread writes (none when kl > WG: tau stays 0).  The cut goes 256 fp32 ulps
-    // (>= 3 EPS) BELOW that value: everything below the cut is then bounded by theta = tau (1 + 2 EPS) <= m (1 - EPS),
-    // which the candidates that tie with m (in the near-tie regime: the whole cluster group the cut falls into) still
-    // reach with their exact scores -- a cut exactly at m emitted none of them, and the merge could not prove the query.
-    if (rank == kl - 1) s_ctl[CTL_SEL_D] = (int)(m > 0x80000100u ? m - 256u : m);
-    __syncthreads();
-    tau = (uint32_t)s_ctl[CTL_SEL_D];
-  }
-  STAMP(6);  // threshold found
-  {
-    unsigned long long x_ = 0;
-    if constexpr (ABL == 4) {
-#pragma unroll
-      for (int u = 0; u < U; u++) x_ ^= (unsigned long long)__float_as_uint(s32[u]) ^ (unsigned)seq[u] ^ k32[u];
-    }
-    ABLATE(4, x_ + tau);
-  }
-  // ---- 5b. compact the survivors with their exact (dot, nsq): one LDS atomic per wave ------------------------------
-  {
-    int total = 0;
-#pragma unroll
-    for (int u = 0; u < U; u++) total += __popcll(__ballot(k32[u] != 0u && k32[u] >= tau));
-    int base = 0;
-    if ((tid & 63) == 0 && total) base = atomicAdd(&s_ctl[CTL_NSURV], total);
-    base = __shfl(base, 0, 64);
-    const unsigned long long below = (1ull << (tid & 63)) - 1ull;
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const bool sv = k32[u] != 0u && k32[u] >= tau;
-      const unsigned long long m = __ballot(sv);  // (recomputed rather than kept: six live masks cost 12 SGPRs)
-      if (sv) {
-        const int o = base + __popcll(m & below);
-        if (o < SCAP) {
-          const int c = seq[u];
-          const uint32_t pos = (c & 0x10000) ? 0u : s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c]);
-          s_ent[o] = ((unsigned long long)(uint32_t)c << 32) | pos;
-        }
-      }
-      base += __popcll(m);
-    }
-  }
-  __syncthreads();
   // A cut that keeps more than the survivor list holds (many candidates sharing threads with larger ones, or a tie
   // group of more than ~100 identical keys -- which no finer cut could split either) sends the unit to the general
   // path.  (Round 1 re-cut such units with a radix histogram over all keys; it fired too rarely to earn its registers.)
