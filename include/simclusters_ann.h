@@ -109,6 +109,11 @@ typedef struct sann_batch_stats {
 } sann_batch_stats_t;
 
 const char *sann_last_error(void);
+/* Environment advice the library has for its process, "" when none.  Today: batches in flight (sann_batch_run_after,
+ * sann_get_tweet_candidates from several threads) need GPU_MAX_HW_QUEUES >= 8 -- streams that share a hardware queue
+ * execute in order and the overlap is silently lost.  The library sets the variable when it is loaded if the process
+ * has not; this returns (and stderr shows, once) a message if the process chose fewer. */
+const char *sann_runtime_advice(void);
 /* Library self-description, e.g. "simclusters_amd 0.1 gfx950". */
 const char *sann_version(void);
 

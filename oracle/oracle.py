@@ -65,6 +65,10 @@ def lib() -> C.CDLL:
         L.oracle_baseline_run.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(oracle_sann_config), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_baseline_query.restype = C.c_int32
+        L.oracle_baseline_query.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(oracle_sann_config), C.c_int64,
+                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 
@@ -127,6 +131,22 @@ def embedding(ids, scores, truncate=-1):
                     expScaledNorm=L.oracle_embedding_expscalednorm(e))
     finally:
         L.oracle_embedding_free(e)
+
+
+def baseline_query(variant, emb_ids, emb_scores, cfg, now_ms, cluster_ids, list_offsets, tweet_ids, scores):
+    """One query through a cpu_baseline leg (0 = "original", two maps; 1 = "optimized", one map)."""
+    L = lib()
+    emb_ids = np.ascontiguousarray(emb_ids, np.int32)
+    emb_scores = np.ascontiguousarray(emb_scores, np.float64)
+    out_ids = np.zeros(1000, np.int64)
+    out_scores = np.zeros(1000, np.float64)
+    msz = C.c_int32()
+    c = make_config(cfg)
+    n = L.oracle_baseline_query(int(variant), len(emb_ids), _p(emb_ids), _p(emb_scores), C.byref(c), int(now_ms),
+                                len(cluster_ids), _p(np.ascontiguousarray(cluster_ids, np.int32)),
+                                _p(np.ascontiguousarray(list_offsets, np.int64)), _p(np.ascontiguousarray(tweet_ids, np.int64)),
+                                _p(np.ascontiguousarray(scores, np.float64)), _p(out_ids), _p(out_scores), C.byref(msz))
+    return out_ids[:n].copy(), out_scores[:n].copy(), msz.value
 
 
 def baseline_run(variant, n_threads, emb_offsets, emb_ids, emb_scores, cfg, now_ms, cluster_ids, list_offsets,

@@ -327,8 +327,9 @@ void oracle_age_window(const oracle_sann_config *cfg, int64_t now_ms, int64_t *e
 /* ------------------------------------------------------------------------------------------
  * Candidate map: open addressing keyed by tweet id, insertion-ordered entries.
  * "original" keeps two maps (scores, normalisation); the arithmetic is identical, so a single
- * entry array holds both accumulators.  (The cpu_baseline twin in oracle_baseline.c keeps the
- * two-map / one-map cost difference; here only results matter.)
+ * entry array holds both accumulators: here only results matter.  (bench.py's cpu_baseline does NOT time
+ * this function: oracle_baseline.c restates the two-map "original" and the one-map "optimized" with their
+ * own probe counts, and a test checks that both give exactly this function's answers.)
  * ---------------------------------------------------------------------------------------- */
 typedef struct { int64_t id; double dot; double nsq; } cand;
 typedef struct { cand *e; int32_t n, cap_e; int32_t *slot; uint32_t mask; } candmap;

@@ -70,3 +70,25 @@ def test_config_struct_layout_matches_header(pkg):
 def test_missing_library_fails_loudly(pkg, tmp_path):
     with pytest.raises(FileNotFoundError):
         pkg.load_library(str(tmp_path / "nope.so"))
+
+
+def test_jni_glue_compiles_against_the_minimal_jni_header():
+    """the JNI glue of INTEGRATION.md is real C, compile-checked against a hand-declared JNI
+    subset (no JDK in this image) and link-checked against the library: every C-ABI symbol it calls exists."""
+    import subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jni = os.path.join(root, "the-algorithm_amd", "jni")
+    src = os.path.join(jni, "simclusters_ann_jni.c")
+    subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-DSANN_JNI_MINIMAL", "-I", jni, src], check=True)
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "libsimclusters_ann_jni.so")
+        subprocess.run(["gcc", "-shared", "-fPIC", "-DSANN_JNI_MINIMAL", "-I", jni, src, "-o", out, "-L", os.path.join(root, "the-algorithm_amd"),
+                        "-lsimclusters_amd", "-Wl,--no-undefined", "-Wl,--allow-shlib-undefined"], check=True)
+        syms = subprocess.run(["nm", "-D", "--defined-only", out], check=True, capture_output=True, text=True).stdout
+        for name in ("indexBuild", "indexDestroy", "hostAlloc", "hostFree", "getTweetCandidates0"):
+            assert f"Java_com_twitter_simclustersann_gpu_SannJni_{name}" in syms
+
+
+def test_library_sets_the_hardware_queue_default_when_loaded(pkg):
+    lib = pkg.load_library()
+    assert os.environ.get("GPU_MAX_HW_QUEUES") is not None or lib.sann_runtime_advice() is not None

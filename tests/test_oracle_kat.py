@@ -85,3 +85,27 @@ def test_embedding_constructor(oracle):
     assert e["l2norm"] == math.sqrt(5.0 * 5.0 + 2.0 * 2.0 + 2.0 * 2.0)
     t = oracle.embedding([7, 3, 9], [2.0, 5.0, 2.0], truncate=2)
     assert list(t["clusterIds"]) == [3, 7]
+
+
+def test_baseline_legs_equal_the_oracle(oracle):
+    """bench.py's cpu_baseline legs (two-map "original", one-map "optimized", oracle/oracle_baseline.c) give exactly the
+    oracle's answers: what is timed is the reference's algorithm, not something cheaper."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from _pkg import load_package
+    pkg = load_package()
+    co = pkg.corpus.make_corpus(20000, 800, seed=3, index_cap=300)
+    co.tweet_ids[5] = 0  # a tweet id 0: "optimized" drops it, "original" keeps it
+    offs, cids, scs = pkg.corpus.make_queries(12, 800, seed=4, clusters_per_user=40)
+
+    class Cfg:
+        maxNumResults, minScore, candidateEmbeddingType = 200, 0.0, 0
+        maxTopTweetsPerCluster, maxScanClusters, maxTweetCandidateAgeHours, minTweetCandidateAgeHours = 150, 30, 175200, 0
+    for alg in (1, 2, 3, 4):
+        Cfg.annAlgorithm = alg
+        for variant in (0, 1):
+            for q in range(12):
+                e_i, e_s = cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]]
+                a = oracle.baseline_query(variant, e_i, e_s, Cfg, co.now_ms, co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores)
+                b = oracle.sann_query(e_i, e_s, None, Cfg, co.now_ms, co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, variant=variant)
+                assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.int64), b[1].view(np.int64))

@@ -1,0 +1,121 @@
+/*
+ * simclusters_ann_jni.c -- JNI glue between the JVM shim of INTEGRATION.md (class
+ * com.twitter.simclustersann.gpu.SannJni) and the C ABI of include/simclusters_ann.h.
+ *
+ * The reference's only JNI precedent is swig-faiss: a raw native handle held as a Java long and calls that take
+ * primitive arrays (ann/src/main/java/com/twitter/ann/faiss/swig/swigfaissJNI.java:13-23,269; Index.java:11-37).
+ * This file follows that shape.  Per-request buffers are direct ByteBuffers owned by the caller, which avoids the
+ * lifetime hazard QueryableIndexAdapter.scala:128-132 documents (the JVM freeing `distances` during the call).
+ *
+ * All logic lives behind the C ABI (which the test-suite exercises); this file only converts argument types and
+ * turns a non-zero status into a RuntimeException -- which the controller already maps to an empty response and a
+ * failures/<class> counter (simclusters-ann/.../controllers/SimClustersANNController.scala:70-74).
+ *
+ * Build (deployment): cc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include \
+ *                        simclusters_ann_jni.c -L.. -lsimclusters_amd -o libsimclusters_ann_jni.so
+ * Compile check (this image has no JDK): gcc -fsyntax-only -DSANN_JNI_MINIMAL ... (tests/test_abi_cpu.py).
+ */
+#ifdef SANN_JNI_MINIMAL
+#include "jni_min.h"
+#else
+#include <jni.h>
+#endif
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/simclusters_ann.h"
+
+static void throw_runtime(JNIEnv *env, const char *msg) {
+  jclass cls = (*env)->FindClass(env, "java/lang/RuntimeException");
+  if (cls) (*env)->ThrowNew(env, cls, msg ? msg : "simclusters_amd: native failure");
+}
+
+/* long indexBuild(int device, int partitions, int shardId, int nShards,
+ *                 int[] clusterIds, long[] listOffsets, long[] tweetIds, double[] scores)
+ * The lists as ClusterTweetIndexProviderModule's store returns them (ClusterTweetIndexProviderModule.scala:34-94). */
+JNIEXPORT jlong JNICALL Java_com_twitter_simclustersann_gpu_SannJni_indexBuild(JNIEnv *env, jclass cls, jint device,
+                                                                                jint partitions, jint shardId, jint nShards,
+                                                                                jintArray clusterIds, jlongArray listOffsets,
+                                                                                jlongArray tweetIds, jdoubleArray scores) {
+  (void)cls;
+  sann_index_options_t o = {device, partitions, shardId, nShards};
+  const jsize n = (*env)->GetArrayLength(env, clusterIds);
+  if ((*env)->GetArrayLength(env, listOffsets) != n + 1) {
+    throw_runtime(env, "listOffsets must have clusterIds.length + 1 entries");
+    return 0;
+  }
+  /* pinned, no copy; nothing between Get and Release may call back into the JVM */
+  void *c = (*env)->GetPrimitiveArrayCritical(env, clusterIds, NULL);
+  void *of = (*env)->GetPrimitiveArrayCritical(env, listOffsets, NULL);
+  void *t = (*env)->GetPrimitiveArrayCritical(env, tweetIds, NULL);
+  void *s = (*env)->GetPrimitiveArrayCritical(env, scores, NULL);
+  sann_index_t *ix = NULL;
+  int rc = SANN_ENOMEM;
+  if (c && of && t && s) rc = sann_index_build(&o, n, (const int32_t *)c, (const int64_t *)of, (const int64_t *)t, (const double *)s, &ix);
+  if (s) (*env)->ReleasePrimitiveArrayCritical(env, scores, s, JNI_ABORT);
+  if (t) (*env)->ReleasePrimitiveArrayCritical(env, tweetIds, t, JNI_ABORT);
+  if (of) (*env)->ReleasePrimitiveArrayCritical(env, listOffsets, of, JNI_ABORT);
+  if (c) (*env)->ReleasePrimitiveArrayCritical(env, clusterIds, c, JNI_ABORT);
+  if (rc != SANN_OK) {
+    throw_runtime(env, rc == SANN_ENOMEM && !(c && of && t && s) ? "could not pin the list arrays" : sann_last_error());
+    return 0;
+  }
+  return (jlong)(intptr_t)ix;
+}
+
+JNIEXPORT void JNICALL Java_com_twitter_simclustersann_gpu_SannJni_indexDestroy(JNIEnv *env, jclass cls, jlong index) {
+  (void)env;
+  (void)cls;
+  sann_index_destroy((sann_index_t *)(intptr_t)index);
+}
+
+/* ByteBuffer hostAlloc(long bytes): pinned memory for the request / response buffers the shim keeps across calls
+ * (device copies then run at PCIe speed); freed with hostFree(buffer). */
+JNIEXPORT jobject JNICALL Java_com_twitter_simclustersann_gpu_SannJni_hostAlloc(JNIEnv *env, jclass cls, jlong bytes) {
+  (void)cls;
+  void *p = NULL;
+  if (sann_host_alloc(bytes, &p) != SANN_OK) {
+    throw_runtime(env, sann_last_error());
+    return NULL;
+  }
+  return (*env)->NewDirectByteBuffer(env, p, bytes);
+}
+JNIEXPORT void JNICALL Java_com_twitter_simclustersann_gpu_SannJni_hostFree(JNIEnv *env, jclass cls, jobject buffer) {
+  (void)cls;
+  if (buffer) sann_host_free((*env)->GetDirectBufferAddress(env, buffer));
+}
+
+/* int getTweetCandidates0(long index, int variant, long nowMs, int nq, int nConfigs,
+ *                         ByteBuffer embOffsets, embClusterIds, embScores, sourceTweetIds, hasSourceTweet, configs,
+ *                         scanOffsets, scanClusterIds, outIds, outScores, int outStride, outCounts, outMapSizes)
+ * = ApproximateCosineSimilarity.apply for nq micro-batched requests (ApproximateCosineSimilarity.scala:26-36).
+ * All buffers are direct, little-endian, caller-owned; sourceTweetIds / hasSourceTweet / scanOffsets /
+ * scanClusterIds may be null.  `configs` holds nConfigs (1 or nq) sann_config_t records of 40 bytes. */
+JNIEXPORT jint JNICALL Java_com_twitter_simclustersann_gpu_SannJni_getTweetCandidates0(
+    JNIEnv *env, jclass cls, jlong index, jint variant, jlong nowMs, jint nq, jint nConfigs, jobject embOffsets,
+    jobject embClusterIds, jobject embScores, jobject sourceTweetIds, jobject hasSourceTweet, jobject configs,
+    jobject scanOffsets, jobject scanClusterIds, jobject outIds, jobject outScores, jint outStride, jobject outCounts,
+    jobject outMapSizes) {
+  (void)cls;
+#define BUF(x) ((x) ? (*env)->GetDirectBufferAddress(env, (x)) : NULL)
+  if (!embOffsets || !configs || !outIds || !outScores || !outCounts || !outMapSizes) {
+    throw_runtime(env, "a required direct buffer is null");
+    return SANN_EINVAL;
+  }
+  if ((*env)->GetDirectBufferCapacity(env, configs) < (jlong)nConfigs * (jlong)sizeof(sann_config_t) ||
+      (*env)->GetDirectBufferCapacity(env, outIds) < (jlong)nq * outStride * 8 ||
+      (*env)->GetDirectBufferCapacity(env, outScores) < (jlong)nq * outStride * 8 ||
+      (*env)->GetDirectBufferCapacity(env, outCounts) < (jlong)nq * 4 ||
+      (*env)->GetDirectBufferCapacity(env, outMapSizes) < (jlong)nq * 4) {
+    throw_runtime(env, "a direct buffer is smaller than the batch needs");
+    return SANN_EINVAL;
+  }
+  const int rc = sann_get_tweet_candidates(
+      (sann_index_t *)(intptr_t)index, variant, nowMs, nq, (const int64_t *)BUF(embOffsets), (const int32_t *)BUF(embClusterIds),
+      (const double *)BUF(embScores), (const int64_t *)BUF(sourceTweetIds), (const uint8_t *)BUF(hasSourceTweet),
+      (const sann_config_t *)BUF(configs), nConfigs, (const int64_t *)BUF(scanOffsets), (const int32_t *)BUF(scanClusterIds),
+      (int64_t *)BUF(outIds), (double *)BUF(outScores), outStride, (int32_t *)BUF(outCounts), (int32_t *)BUF(outMapSizes));
+#undef BUF
+  if (rc != SANN_OK) throw_runtime(env, sann_last_error());
+  return rc;
+}

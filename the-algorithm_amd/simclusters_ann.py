@@ -138,6 +138,7 @@ _lib = None
 _PROTOS = {
     "sann_last_error": (C.c_char_p, []),
     "sann_version": (C.c_char_p, []),
+    "sann_runtime_advice": (C.c_char_p, []),
     "sann_index_build": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "sann_index_build_synthetic": (C.c_int, [C.POINTER(sann_index_options_t), C.POINTER(sann_synth_params_t), C.POINTER(C.c_void_p)]),
     "sann_synth_tweet_embeddings": (C.c_int, [C.c_int32, C.POINTER(sann_synth_params_t), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
