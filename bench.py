@@ -102,6 +102,14 @@ def main():
     # merge (one shard), so the RCCL plumbing of the N > 1 path can be checked on a 1-GPU box
     sharded = world > 1 or args.exercise_exchange
     dist = torch = None
+    json_fd = None
+    if sharded and args.backend != "gloo":
+        # RCCL prints a version banner on STDOUT when the first communicator of the process comes up (through torch's
+        # process group or through the library's own).  This program's stdout is ONE JSON line: file descriptor 1 is
+        # pointed at stderr for the rest of the run and the JSON line goes to a private copy of the original.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
     if sharded:
         for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
             os.environ.setdefault(key, val)
@@ -189,6 +197,18 @@ def main():
             h_stream = ctypes.c_void_p()
             assert hip.hipStreamCreateWithFlags(ctypes.byref(h_stream), 1) == 0  # hipStreamNonBlocking
             streams.append(h_stream.value)
+    comm = None
+    if sharded and args.backend != "gloo":
+        # the library's RCCL communicator; torch.distributed only carries the 128-byte unique id (and the barriers)
+        uid = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            assert lib.sann_comm_unique_id(buf) == 0, lib.sann_last_error()
+            uid[0] = buf.raw
+        dist.broadcast_object_list(uid, src=0)
+        comm = ctypes.c_void_p()
+        rc = lib.sann_comm_create(local_rank, rank, world, uid[0], ctypes.byref(comm))
+        assert rc == 0, lib.sann_last_error()
     inexact_seen = 0
     while True:
         cfg_run = cfg if shard_k == K else dataclasses.replace(cfg, maxNumResults=shard_k)
@@ -228,22 +248,24 @@ def main():
             d_bad = torch.zeros(1, dtype=torch.int32, device="cuda")  # queries whose cut per-shard lists could not prove the merge exact
             torch.cuda.synchronize()  # the buffers were zero-filled on the default stream; they are used on others
 
-        def exchange(send, recv):
+        def exchange(send, recv, stream_ptr):
             if args.backend == "gloo":  # rehearsal: gloo has no all-to-all; gather on the host and slice
                 h = send.cpu()
                 parts = [torch.zeros_like(h) for _ in range(world)]
                 dist.all_gather(parts, h)
                 c = h.numel() // world
                 recv.copy_(torch.cat([p[rank * c:(rank + 1) * c] for p in parts]))
-            else:
-                dist.all_to_all_single(recv, send)
+            else:  # the library's own RCCL exchange (csrc/sann_comm.hip): what a non-Python worker calls too
+                rc = lib.sann_exchange_to_owners(comm, ctypes.c_void_p(stream_ptr), ctypes.c_void_p(send.data_ptr()),
+                                                 ctypes.c_void_p(recv.data_ptr()), chunk)
+                assert rc == 0, lib.sann_last_error()
 
         def post(slot):
             """Exchange + owner merge of a finished batch, on the side stream."""
             ready[slot].record(t_streams[slot])
             with torch.cuda.stream(side_stream):
                 side_stream.wait_event(ready[slot])
-                exchange(sends[slot], recv)
+                exchange(sends[slot], recv, side_stream.cuda_stream)
                 sent[slot] = torch.cuda.Event()
                 sent[slot].record(side_stream)
                 side = ctypes.c_void_p(side_stream.cuda_stream)
@@ -425,6 +447,8 @@ def main():
     if rank != 0:
         if sharded:
             dist.barrier()
+            if comm is not None:
+                lib.sann_comm_destroy(comm)
             dist.destroy_process_group()
         return
 
@@ -529,9 +553,14 @@ def main():
         "cpu_baseline": cpu,
         "corpus_build_s": t_corpus,
     }
-    print(json.dumps(line))
+    if json_fd is not None:
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    else:
+        print(json.dumps(line), flush=True)
     if sharded:
         dist.barrier()
+        if comm is not None:
+            lib.sann_comm_destroy(comm)
         dist.destroy_process_group()
 
 

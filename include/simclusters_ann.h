@@ -309,6 +309,30 @@ int sann_merge_shards_cut(int32_t device, void *hip_stream, int32_t n_shards, in
                           const void *d_scores, const void *d_counts, const void *d_map_sizes, void *d_out_ids,
                           void *d_out_scores, void *d_out_counts, void *d_out_map_sizes, void *d_inexact_count);
 
+/*
+ * The exchange step of the sharded path, over RCCL (xGMI inside a node): one process per GPU, GPU g holding shard g
+ * (sann_index_options_t.shard_id / n_shards).  Every rank answers the whole batch on its shard with its outputs bound
+ * owner-chunked (sann_batch_bind_outputs_chunked, chunk layout: sann_owner_message_layout), sann_exchange_to_owners
+ * delivers chunk r of every rank's buffer to rank r -- ONE all-to-all per batch, a group of ncclSend / ncclRecv on the
+ * caller's stream -- and the owner merges what it received with sann_merge_shards / sann_merge_shards_cut
+ * (shard_pitch_bytes = the chunk size).  The reference's pattern: ComposedQueryable, ann/.../common/ShardApi.scala:71-87.
+ * No Python or torch involved: rank 0 calls sann_comm_unique_id, ships the 128 bytes to the other ranks over any
+ * control channel, every rank calls sann_comm_create (collective: all ranks must call it).
+ */
+typedef struct sann_comm sann_comm_t;
+int sann_comm_unique_id(void *id128 /* out: 128 bytes (an ncclUniqueId) */);
+int sann_comm_create(int32_t device, int32_t rank, int32_t world, const void *id128, sann_comm_t **out);
+int sann_comm_info(const sann_comm_t *comm, int32_t *rank, int32_t *world);
+int sann_comm_destroy(sann_comm_t *comm);
+/* d_send = [world][chunk_bytes] (chunk r is for rank r), d_recv = [world][chunk_bytes] (chunk s came from rank s);
+ * asynchronous on hip_stream. */
+int sann_exchange_to_owners(sann_comm_t *comm, void *hip_stream, const void *d_send, void *d_recv, int64_t chunk_bytes);
+/* Byte layout of one owner's message for queries_per_owner queries of `stride` entries: ids at 0, score bits at
+ * *off_scores, counts at *off_counts, map sizes at *off_map_sizes; *chunk_bytes in all (a multiple of 8).  Pure host
+ * arithmetic. */
+int sann_owner_message_layout(int32_t queries_per_owner, int32_t stride, int64_t *chunk_bytes, int64_t *off_scores,
+                              int64_t *off_counts, int64_t *off_map_sizes);
+
 /* Make the merge kernel write the final results into caller-owned device buffers (e.g. torch
  * tensors that feed an all-gather) instead of the batch's own; pass four NULLs to unbind.
  * Sizes: int64[nq*stride], double[nq*stride], int32[nq], int32[nq], stride as reported by

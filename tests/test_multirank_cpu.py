@@ -137,3 +137,17 @@ def test_cut_list_merge_proof_rule(pkg):
     # equal scores: the smaller tweet id ranks first
     tie = merge(np.array([[7], [5]], np.int64), np.array([[1.0], [1.0]]), np.array([1, 1]), 1, 4)
     assert tie[0].tolist() == [5] and tie[2] is True
+
+
+def test_c_message_layout_is_the_layout_the_exchange_tests_use(pkg):
+    """sann_owner_message_layout (what a non-Python worker calls to bind its outputs and size the exchange) against the
+    numpy layout the 2-rank gloo test above packs and merges with."""
+    import ctypes as C
+    lib = pkg.load_library()
+    for nql, stride in ((1, 1), (3, 7), (512, 104), (1024, 400), (1000, 1000)):
+        chunk, o_sc, o_cnt, o_msz = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        assert lib.sann_owner_message_layout(nql, stride, C.byref(chunk), C.byref(o_sc), C.byref(o_cnt), C.byref(o_msz)) == 0
+        size, (p_ids, p_sc, p_cnt, p_msz) = pkg.sharding.owner_message_layout(nql, stride)
+        assert (chunk.value, o_sc.value, o_cnt.value, o_msz.value) == (size, p_sc, p_cnt, p_msz) and p_ids == 0
+        assert chunk.value % 8 == 0
+    assert lib.sann_owner_message_layout(-1, 4, None, None, None, None) == 1  # SANN_EINVAL
