@@ -43,6 +43,14 @@ extern "C" {
 #define SANN_ALG_COSINE 2
 #define SANN_ALG_LOG_COSINE 3
 #define SANN_ALG_COSINE_NO_SOURCE_NORM 4
+/* The offline all-users job (src/scala/com/twitter/simclusters_v2/scio/bq_generation/sql/tweets_ann.sql:44-52,
+ * tweets_ann/TweetsANNFromBQ.scala:17-21): same top-N clusters x top-M tweets x dot product, but normalised by the
+ * tweet's FULL embedding norm (:10-15) and not by the source: logCosineSimilarityScore = dot / LN(1 + norm) -- the
+ * job's ranking key (:57-58) -- and cosineSimilarityScore = dot / SQRT(norm); dotProductScore is SANN_ALG_DOT_PRODUCT.
+ * They need an index built with sann_index_build_with_norms; tweets whose norm is not > 0 are dropped (:14); the
+ * job has no age window (max / min_tweet_candidate_age_hours are ignored). */
+#define SANN_ALG_OFFLINE_LOG_COSINE 5
+#define SANN_ALG_OFFLINE_COSINE 6
 
 /* Which reference implementation's edge-case behaviour to reproduce (they agree on every
  * input that SimClustersANNCandidateSource can produce):
@@ -133,6 +141,12 @@ const char *sann_version(void);
 int sann_index_build(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
                      const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores,
                      sann_index_t **out);
+/* The same with a per-posting norms column for the offline job's scores (SANN_ALG_OFFLINE_*): tweet_norms[i] = SUM of
+ * squares of the FULL embedding of the tweet of posting i (tweets_ann.sql:10-15: tweet_embeddings_norm, which the job
+ * joins by tweet id -- here the caller has joined it onto the postings). */
+int sann_index_build_with_norms(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
+                                const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores,
+                                const double *tweet_norms, sann_index_t **out);
 /*
  * Generate the synthetic SimClusters corpus of SURVEY.md section 8(d) on the device and build
  * the index from it without a host round trip (per-cluster filter -> sort by score descending

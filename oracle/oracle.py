@@ -261,3 +261,56 @@ def hnsw_search(metric: int, stored: np.ndarray, graph, query: np.ndarray, k: in
                              C.c_int32(max_level), C.c_int64(len(lv)), _p(lv), _p(it), _p(off), _p(nb), C.c_int32(k), C.c_int32(ef),
                              _p(out_i), _p(out_d), C.byref(evals))
     return out_i[:m].copy(), out_d[:m].copy(), evals.value
+
+
+# ---------------------------------------------------------------------------------------------
+# The offline all-users job: src/scala/com/twitter/simclusters_v2/scio/bq_generation/sql/tweets_ann.sql:1-64, restated
+# step by step in plain Python (small inputs only).  It is the reference's only INDEPENDENT statement of the
+# algorithm (a SQL text, not the Scala operator), so besides pinning the offline scores it cross-checks the
+# operator oracle: both must give a (user, tweet) pair the same dot product.
+# Orders BigQuery leaves open are fixed as everywhere else: ORDER BY ... DESC ties by id ascending; SUM adds in
+# ascending cluster id.
+# ---------------------------------------------------------------------------------------------
+def tweets_ann_sql(consumer_embeddings, tweet_embeddings, top_n, top_m, top_k):
+    """consumer_embeddings: {userId: [(clusterId, userScore)]}; tweet_embeddings: {tweetId: [(clusterId, tweetScore)]}.
+    Returns {userId: [(tweetId, dotProductScore, cosineSimilarityScore, logCosineSimilarityScore)]} ordered by
+    logCosineSimilarityScore DESC, at most top_k entries (:55-60)."""
+    import math
+
+    # :10-15 tweet_embeddings_norm: SUM(tweetScore * tweetScore) ... HAVING norm > 0.0
+    norm = {}
+    for t, emb in tweet_embeddings.items():
+        total = 0.0
+        for _c, s in sorted(emb):
+            total = total + s * s
+        if total > 0.0:
+            norm[t] = total
+    # :17-21 top N clusters per consumer embedding, ORDER BY userScore DESC LIMIT N
+    top_clusters = {u: sorted(emb, key=lambda cs: (-cs[1], cs[0]))[:max(top_n, 0)] for u, emb in consumer_embeddings.items()}
+    # :23-27 top M tweets per cluster, ORDER BY tweetScore DESC LIMIT M
+    by_cluster = {}
+    for t, emb in tweet_embeddings.items():
+        for c, s in emb:
+            by_cluster.setdefault(c, []).append((t, s))
+    cluster_tweets = {c: sorted(v, key=lambda ts: (-ts[1], ts[0]))[:max(top_m, 0)] for c, v in by_cluster.items()}
+    out = {}
+    for u, clusters in top_clusters.items():
+        # :29-37 join, :39-46 SUM(userScore * tweetScore) GROUP BY userId, tweetId
+        dot = {}
+        for c, user_score in sorted(clusters):  # ascending cluster id = the summation order
+            for t, tweet_score in cluster_tweets.get(c, []):
+                dot[t] = dot.get(t, 0.0) + user_score * tweet_score
+        # :47-54 similarity scores; the JOIN drops tweets without a norm row
+        rows = []
+        for t, d in dot.items():
+            if t not in norm:
+                continue
+            rows.append((t, d, d / math.sqrt(norm[t]), d / strict_log(1 + norm[t])))
+        # :55-60 top K ORDER BY logCosineSimilarityScore DESC
+        rows.sort(key=lambda r: (-r[3], r[0]))
+        out[u] = rows[:max(top_k, 0)]
+    return out
+
+
+def strict_log(x: float) -> float:
+    return float(lib().oracle_strict_log(float(x)))

@@ -146,11 +146,23 @@ int prepare_query_host(const sann_index *ix, int variant, int64_t now_ms, const 
   int k = cfg.max_num_results < 1000 ? cfg.max_num_results : 1000;
   h.k = k < 0 ? 0 : k;
   h.alg = cfg.ann_algorithm;
+  h.use_norms = 0;
+  h.reserved = 0;
   // age window (ApproximateCosineSimilarity.scala:65-72)
   h.earliest = (cfg.max_tweet_candidate_age_hours >= 175200 && variant != SANN_VARIANT_LEGACY)
                    ? 0
                    : snowflake_first_id_for(now_ms - (int64_t)cfg.max_tweet_candidate_age_hours * 3600000ll);
   h.latest = snowflake_first_id_for(now_ms - (int64_t)cfg.min_tweet_candidate_age_hours * 3600000ll);
+  if (cfg.ann_algorithm == SANN_ALG_OFFLINE_LOG_COSINE || cfg.ann_algorithm == SANN_ALG_OFFLINE_COSINE) {
+    // tweets_ann.sql:44-52: dot / LN(1 + norm) and dot / SQRT(norm) with the tweet's FULL norm and no source norm:
+    // the log form with logNorm = 1, the no-source-norm cosine form, both with nsq taken from the norms column;
+    // the job has no age window
+    h.alg = cfg.ann_algorithm == SANN_ALG_OFFLINE_LOG_COSINE ? SANN_ALG_LOG_COSINE : SANN_ALG_COSINE_NO_SOURCE_NORM;
+    h.lognorm = 1.0;
+    h.use_norms = 1;
+    h.earliest = std::numeric_limits<int64_t>::min();
+    h.latest = std::numeric_limits<int64_t>::max();
+  }
   // source-tweet exclusion (:90 ; Optimized :56,:67 ; Experimental :59,:70)
   if (variant == SANN_VARIANT_ORIGINAL || variant == SANN_VARIANT_LEGACY) {
     h.excl_enabled = has_src ? 1 : 0;
@@ -325,9 +337,9 @@ const char *sann_version(void) { return "simclusters_amd 0.1 (gfx950, fp64 parit
 // ---------------------------------------------------------------------------------------------
 // index
 // ---------------------------------------------------------------------------------------------
-int sann_index_build(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
-                     const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores,
-                     sann_index_t **out) {
+static int index_build_impl(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
+                            const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores,
+                            const double *tweet_norms, sann_index_t **out) {
   if (!out) return fail(SANN_EINVAL, "out is NULL");
   *out = nullptr;
   if (!opts) return fail(SANN_EINVAL, "opts is NULL");
@@ -402,6 +414,7 @@ int sann_index_build(const sann_index_options_t *opts, int32_t n_lists, const in
   // pass 2: fill, keeping list order inside every sub-list (ranks ascending)
   std::vector<Posting> h_post((size_t)run);
   std::vector<uint32_t> h_rank((size_t)run);
+  std::vector<double> h_norm(tweet_norms ? (size_t)run : 0);
   std::vector<uint32_t> cursor(ix->h_sub_offsets.begin(), ix->h_sub_offsets.end() - 1);
   for (int32_t r = 0; r < n_lists; r++) {
     int64_t b = list_offsets[r], e = list_offsets[r + 1];
@@ -411,6 +424,7 @@ int sann_index_build(const sann_index_options_t *opts, int32_t n_lists, const in
       uint32_t &c = cursor[(size_t)r * P + tweet_partition(h, (uint32_t)P)];
       h_post[c].id = tweet_ids[i];
       h_post[c].score = scores[i];
+      if (tweet_norms) h_norm[c] = tweet_norms[i];
       h_rank[c] = (uint32_t)std::min<int64_t>(i - b, 0xffffffffll);
       c++;
     }
@@ -427,6 +441,11 @@ int sann_index_build(const sann_index_options_t *opts, int32_t n_lists, const in
   if (e == hipSuccess)
     e = hipMemcpy(ix->sub_offsets.p, ix->h_sub_offsets.data(), ix->h_sub_offsets.size() * sizeof(uint32_t),
                   hipMemcpyHostToDevice);
+  if (e == hipSuccess && tweet_norms) {
+    e = ix->norms.alloc(std::max<size_t>(h_norm.size(), 1) * sizeof(double));
+    if (e == hipSuccess && !h_norm.empty())
+      e = hipMemcpy(ix->norms.p, h_norm.data(), h_norm.size() * sizeof(double), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     delete ix;
     return fail(SANN_EDEVICE, std::string("index upload: ") + hipGetErrorString(e));
@@ -435,12 +454,26 @@ int sann_index_build(const sann_index_options_t *opts, int32_t n_lists, const in
   return SANN_OK;
 }
 
+int sann_index_build(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
+                     const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores, sann_index_t **out) {
+  return index_build_impl(opts, n_lists, cluster_ids, list_offsets, tweet_ids, scores, nullptr, out);
+}
+
+int sann_index_build_with_norms(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
+                                const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores,
+                                const double *tweet_norms, sann_index_t **out) {
+  if (!tweet_norms && n_lists > 0 && list_offsets && list_offsets[n_lists] > list_offsets[0])
+    return fail(SANN_EINVAL, "tweet_norms is NULL");
+  static const double none = 0.0;
+  return index_build_impl(opts, n_lists, cluster_ids, list_offsets, tweet_ids, scores, tweet_norms ? tweet_norms : &none, out);
+}
+
 int sann_index_info(const sann_index_t *ix, sann_index_info_t *info) {
   if (!ix || !info) return fail(SANN_EINVAL, "NULL argument");
   info->n_clusters = (int64_t)ix->cluster_ids.size();
   info->n_postings = ix->n_postings;
   info->n_postings_total = ix->n_postings_total;
-  info->device_bytes = (int64_t)(ix->postings.bytes + ix->ranks.bytes + ix->sub_offsets.bytes);
+  info->device_bytes = (int64_t)(ix->postings.bytes + ix->ranks.bytes + ix->sub_offsets.bytes + ix->norms.bytes);
   info->n_partitions = ix->P;
   info->shard_id = ix->shard_id;
   info->n_shards = ix->n_shards;
@@ -512,6 +545,7 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
 
   // ---- O(nq) pass over the arguments: validation, the scan regions' upper bounds, k, M ----------------------------
   int kmax = 1;
+  bool any_norms = false;
   int64_t max_emb = 0, total_ub = 0;
   int max_ub = 0;
   double apriori_mean = 0.0;  // largest expected unit size over the queries (see the geometry note below)
@@ -525,6 +559,11 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
     }
     int k = cfg.max_num_results < 1000 ? cfg.max_num_results : 1000;
     kmax = std::max(kmax, k);
+    if (cfg.ann_algorithm == SANN_ALG_OFFLINE_LOG_COSINE || cfg.ann_algorithm == SANN_ALG_OFFLINE_COSINE) {
+      if (!ix->norms.p) return fail(SANN_EINVAL, "offline scoring needs an index built with sann_index_build_with_norms");
+      if (variant == SANN_VARIANT_LEGACY) return fail(SANN_EINVAL, "offline scoring is not a form of the legacy variant");
+      any_norms = true;
+    }
   }
   HIP_TRY(hipSetDevice(ix->device));
   // staging layout (one pinned block, one H2D copy)
@@ -675,6 +714,7 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
   }
   b->fast.k_local = 0;
   b->fast.max_n_scan = max_ub;
+  b->fast.use_norms = any_norms ? 1 : 0;
 
   if (b->device_prep) {
     // ---- device path: upload the packed inputs, prepare on the GPU ------------------------------------------------

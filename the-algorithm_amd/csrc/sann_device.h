@@ -35,14 +35,19 @@ struct QueryHdr {
   int32_t n_scan;     // clusters to scan, in accumulation order
   int32_t M;          // max(maxTopTweetsPerCluster, 0)
   int32_t k;          // min(max(maxNumResults,0), 1000)
-  int32_t alg;        // SANN_ALG_*
+  int32_t alg;        // SANN_ALG_* (1..4; the offline forms 5 / 6 arrive as 3 / 4 with use_norms)
   int32_t excl_enabled;
+  // offline job (scio/bq_generation/sql/tweets_ann.sql:10-15,50-51): the candidate's normaliser is its tweet's FULL
+  // embedding norm -- the per-posting norms column of the index -- instead of the sum of squares over scanned clusters
+  int32_t use_norms;
+  int32_t reserved;
 };
 
 struct IndexView {
   const Posting *postings;
   const uint32_t *ranks;
   const uint32_t *sub_offsets;
+  const double *norms;  // [n_postings] sum of squares of the posting's tweet's FULL embedding, or NULL (online index)
   int32_t n_rows;
   int32_t P;      // partitions (power of two)
   int32_t log2P;

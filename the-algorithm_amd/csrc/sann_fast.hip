@@ -264,13 +264,11 @@ enum {
 // NS = scanned clusters the unit's tables hold (64 when the batch's queries scan at most 64 -- the production N is 50 --
 // else NSCAN_MAX): with the match list moved into the dead Bloom filter's memory the six-slot geometry then needs
 // 20.0 KB of LDS and 64 registers, i.e. EIGHT workgroups per CU (the hardware's 32 waves) instead of six.
-template <int WG, int U, int NS = NSCAN_MAX, int ABL = 0>
-#ifdef SANN_EXP_LB6
-#define SANN_LB6_ 8
-#else
-#define SANN_LB6_ 8
-#endif
-__global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5 : U <= 12 ? 3 : 2)) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
+// NORMS = the batch holds queries of the offline job's forms (QueryHdr.use_norms): a candidate's normaliser is the
+// norms column of the index, carried as a seventh fp32 per posting -- a separate instantiation, so that the online
+// kernel's 64 registers are not touched.
+template <int WG, int U, int NS = NSCAN_MAX, int ABL = 0, bool NORMS = false>
+__global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <= 6 ? 8 : U <= 8 ? 5 : U <= 12 ? 3 : 2)) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
   constexpr int SCAP = FAST_SCAP;
   constexpr int BW = bloom_log2(WG * U);  // log2 of the Bloom filter's 64-bit words
   constexpr int BLOOM_ALLOC = 1 << BW;
@@ -306,6 +304,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
   __shared__ long long s_Mid_own[ALIAS_M ? 1 : MCAP];
   __shared__ double s_Msc_own[ALIAS_M ? 1 : MCAP], s_Mdot_own[ALIAS_M ? 1 : MCAP], s_Mnsq_own[ALIAS_M ? 1 : MCAP];
   __shared__ int s_Mseq_own[ALIAS_M ? 1 : MCAP], s_Mrole_own[ALIAS_M ? 1 : MCAP];
+  __shared__ double s_Mnrm[NORMS ? MCAP : 1];  // offline forms: the full norm of the match-list entry's tweet
   // survivor list: (cluster sequence number or 0x10000 | match-list entry) << 32 | position of the posting in the index
   unsigned long long *const s_ent = ALIAS ? s_bloom : s_ent_own;
   unsigned *const s_hist = ALIAS ? reinterpret_cast<unsigned *>(s_bloom + SCAP) : s_hist_own;
@@ -390,7 +389,8 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
   // Cosine forms: a single-cluster candidate's key is a constant of its cluster, so WHERE to cut can be decided from
   // the descriptors alone -- clusters by key, postings counted until kl are covered -- before a single posting has
   // arrived: wave 0 does that in the shadow of the posting loads (5a'), and the data-dependent cut (5a) is skipped.
-  const bool pre_cut = (h.alg == 2 || h.alg == 4) && h.n_scan <= 64 && !overflow;  // uniform
+  const bool use_norms = NORMS && h.use_norms != 0;  // uniform
+  const bool pre_cut = (h.alg == 2 || h.alg == 4) && h.n_scan <= 64 && !overflow && !use_norms;  // uniform
 
   // ---- 2. gather ---------------------------------------------------------------------------------------
   // A posting is looked at ONCE: window / source filters on its id, three Bloom bits from a hash of its id, and its
@@ -398,6 +398,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
   // -- not the 16-byte posting: the few that survive the cut (~4 %) are fetched again (from L2) for their exact
   // fp64 arithmetic.  With the 16-byte form resident, six slots did not fit 80 registers and hipcc kept two of them
   // in scratch memory, re-reading them in every later phase.
+  float nrm32[NORMS ? U : 1];  // offline forms: the tweet's full norm, fp32
   float s32[U];   // posting score, fp32
   int seq[U];     // cluster sequence number; bit 16 = group representative (low bits: match-list entry); < 0 = no candidate here
   int live = 0;
@@ -483,9 +484,19 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
         const bool excluded = h.excl_enabled != 0 && idv == h.src_excl;  // :90
         const bool in_window = idv >= h.earliest && idv <= h.latest;     // :91
         const bool keep = have && !excluded && in_window;
-        seq[u] = keep ? seq[u] : -1;
+        bool keep_n = keep;
+        if constexpr (NORMS) {
+          nrm32[u] = 1.f;
+          if (use_norms) {
+            const int c = have ? seq[u] : 0;
+            const double nrm = have ? ix.norms[s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c])] : 0.0;
+            nrm32[u] = (float)nrm;
+            keep_n = keep && nrm > 0.0;  // tweets_ann.sql:14  HAVING norm > 0.0
+          }
+        }
+        seq[u] = keep_n ? seq[u] : -1;
         s32[u] = (float)scv;
-        live += __popcll(__ballot(keep));  // wave count, identical in all lanes
+        live += __popcll(__ballot(keep_n));  // wave count, identical in all lanes
         hsh[u] = table_hash(idv, HB);
       }
     }
@@ -555,6 +566,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
             s_Mid[m] = pm.id;
             s_Mseq[m] = c;
             s_Msc[m] = pm.score;
+            if constexpr (NORMS) s_Mnrm[m] = use_norms ? ix.norms[s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c])] : 0.0;
           }
         }
       }
@@ -597,6 +609,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
                 nsq = nsq + bs * bs;         // :95-96
                 last = best;
               }
+              if constexpr (NORMS) nsq = use_norms ? s_Mnrm[m] : nsq;  // one norm per tweet, not a sum over clusters
               s_Mdot[m] = dot;
               s_Mnsq[m] = nsq;
               role = 1;
@@ -639,6 +652,20 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
     if (overflow) {
 #pragma unroll
       for (int u = 0; u < U; u++) k32[u] = 0u;
+    } else if (use_norms) {
+      // offline forms: dot / LN(1 + norm) (as alg 3 with logNorm = 1) and dot / SQRT(norm) (as alg 4), norm = the column
+      if constexpr (NORMS) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const bool lv = seq[u] >= 0;
+          const float n32 = nrm32[u];
+          bool forced;
+          // (below 1e-6 the exact form's rounding of 1 + norm matters: such units take the general path)
+          const float a = approx_score(h.alg, s32[u] * s_w32[lv ? (seq[u] & (NS - 1)) : 0], n32, 1.0, 1.f, 1.f, &forced);
+          bad = bad || (lv && !(seq[u] & 0x10000) && !(a > 1e-30f && a < 1e30f && n32 >= 1e-6f && n32 < 1e30f));
+          k32[u] = lv ? (__float_as_uint(a) | 0x80000000u) : 0u;
+        }
+      }
     } else if (h.alg == 2 || h.alg == 4) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -689,7 +716,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
           const float d32 = (float)s_Mdot[seq[u] & 0xffff], n32 = (float)nsq64;
           bool forced;
           const float a = approx_score(h.alg, d32, n32, nsq64, invl2, invln, &forced);
-          bad = bad || (!forced && !(a > 1e-30f && a < 1e30f && n32 > 1e-30f && n32 < 1e30f));
+          bad = bad || (!forced && !(a > 1e-30f && a < 1e30f && n32 > 1e-30f && n32 < 1e30f)) || (use_norms && (forced || n32 < 1e-6f));
           k32[u] = forced ? FORCED_KEY : (__float_as_uint(a) | 0x80000000u);
         }
       }
@@ -862,6 +889,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : U <= 6 ? SANN_LB6_ : U <= 8 ? 5
       idv = ps.id;
       dot = 0.0 + ps.score * s_w[c];  // getOrElse(tweetId, 0.0) + score * sourceClusterScore  (:92-94)
       nsq = 0.0 + ps.score * ps.score;  // (:95-96)
+      if constexpr (NORMS) nsq = use_norms ? ix.norms[(uint32_t)e] : nsq;  // tweets_ann.sql:50-51
     }
     const double v = normalise_f(h.alg, dot, nsq, h.l2norm, h.lognorm);
     const unsigned long long key = score_key(v);
@@ -890,7 +918,12 @@ static hipError_t launch_one(const IndexView &ix, const BatchView &b, const Fast
   const int nq8 = (b.nq + 7) / 8 * 8;
   const int n_blocks = nq8 * ix.P;
   static const int pad_lds = getenv("SANN_EXP_PAD_LDS") ? atoi(getenv("SANN_EXP_PAD_LDS")) : 0;  // experiment: caps occupancy
-  if (fp.max_n_scan <= 64)
+  if (fp.use_norms) {
+    if (fp.max_n_scan <= 64)
+      hipLaunchKernelGGL((unit_fast_kernel<WG, U, 64, 0, true>), dim3(n_blocks), dim3(WG), 0, stream, ix, b, fp.k_local, n_blocks);
+    else
+      hipLaunchKernelGGL((unit_fast_kernel<WG, U, NSCAN_MAX, 0, true>), dim3(n_blocks), dim3(WG), 0, stream, ix, b, fp.k_local, n_blocks);
+  } else if (fp.max_n_scan <= 64)
     hipLaunchKernelGGL((unit_fast_kernel<WG, U, 64>), dim3(n_blocks), dim3(WG), (size_t)pad_lds, stream, ix, b, fp.k_local, n_blocks);
   else
     hipLaunchKernelGGL((unit_fast_kernel<WG, U, NSCAN_MAX>), dim3(n_blocks), dim3(WG), 0, stream, ix, b, fp.k_local, n_blocks);

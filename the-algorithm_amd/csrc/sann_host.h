@@ -62,7 +62,7 @@ struct sann_index {
   std::vector<uint32_t> h_sub_offsets;  // host copy of the device CSR
   int64_t n_postings = 0, n_postings_total = 0;
   int32_t max_list_len = 0;
-  sann_host::DevBuf postings, ranks, sub_offsets;
+  sann_host::DevBuf postings, ranks, sub_offsets, norms;
   // cut cache: for a given maxTopTweetsPerCluster M, the number of postings with rank < M in every
   // (row, partition) sub-list.  M is a service-level constant in practice, so this is built once
   // (one binary search per sub-list, on the device) and reused by every batch.
@@ -95,6 +95,7 @@ struct sann_index {
     v.postings = postings.as<sann::Posting>();
     v.ranks = ranks.as<uint32_t>();
     v.sub_offsets = sub_offsets.as<uint32_t>();
+    v.norms = norms.as<double>();
     v.n_rows = (int32_t)cluster_ids.size();
     v.P = P;
     v.log2P = log2P;

@@ -57,6 +57,7 @@ struct FastParams {
   int unit_capacity;  // postings one unit holds in registers (workgroup size x postings per thread)
   int k_local;        // floor on the entries a unit must offer before it may withhold the rest
   int max_n_scan;     // largest number of scanned clusters of any query of the batch
+  int use_norms;      // some query of the batch scores with the index's norms column (offline forms)
 };
 hipError_t launch_cut(const IndexView &ix, int M, uint32_t *out, hipStream_t stream);
 hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int max_n_scan, hipStream_t stream);

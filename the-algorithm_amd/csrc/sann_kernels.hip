@@ -227,6 +227,8 @@ __global__ __launch_bounds__(WG) void unit_general_kernel(IndexView ix, BatchVie
       const double s = pst.score;
       if (h.excl_enabled && id == h.src_excl) continue;   // :90
       if (id < h.earliest || id > h.latest) continue;     // :91
+      const double nrm = h.use_norms ? ix.norms[base + j] : 0.0;
+      if (h.use_norms && !(nrm > 0.0)) continue;          // tweets_ann.sql:14  HAVING norm > 0.0
       uint32_t slot;
       bool fresh = false;
       if (id == kEmptyKey) {
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(WG) void unit_general_kernel(IndexView ix, BatchVie
       double d0 = fresh ? 0.0 : dot[slot];  // getOrElse(tweetId, 0.0)
       double n0 = fresh ? 0.0 : nsq[slot];
       dot[slot] = d0 + s * w;               // :92-94
-      nsq[slot] = n0 + s * s;               // :95-96
+      nsq[slot] = h.use_norms ? nrm : n0 + s * s;  // :95-96 ; offline forms: the tweet's full norm (tweets_ann.sql:50-51)
     }
     __syncthreads();
   }

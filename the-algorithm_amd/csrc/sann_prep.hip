@@ -215,10 +215,20 @@ __global__ __launch_bounds__(PWG) void prep_kernel(PrepView in) {
     const int k = cfg.max_num_results < 1000 ? cfg.max_num_results : 1000;
     h.k = k < 0 ? 0 : k;
     h.alg = cfg.ann_algorithm;
+    h.use_norms = 0;
+    h.reserved = 0;
     h.earliest = (cfg.max_tweet_candidate_age_hours >= 175200 && !legacy)
                      ? 0
                      : first_id_for(in.now_ms - (int64_t)cfg.max_tweet_candidate_age_hours * 3600000ll);
     h.latest = first_id_for(in.now_ms - (int64_t)cfg.min_tweet_candidate_age_hours * 3600000ll);
+    if (cfg.ann_algorithm == SANN_ALG_OFFLINE_LOG_COSINE || cfg.ann_algorithm == SANN_ALG_OFFLINE_COSINE) {
+      // tweets_ann.sql:44-52 (see prepare_query_host)
+      h.alg = cfg.ann_algorithm == SANN_ALG_OFFLINE_LOG_COSINE ? SANN_ALG_LOG_COSINE : SANN_ALG_COSINE_NO_SOURCE_NORM;
+      h.lognorm = 1.0;
+      h.use_norms = 1;
+      h.earliest = (int64_t)0x8000000000000000ull;
+      h.latest = 0x7fffffffffffffffll;
+    }
     const bool has_src = in.has_source_tweet && in.has_source_tweet[q] && in.source_tweet_ids;
     if (in.variant == SANN_VARIANT_ORIGINAL || legacy) {
       h.excl_enabled = has_src ? 1 : 0;

@@ -32,6 +32,9 @@ class ScoringAlgorithm(enum.IntEnum):
     CosineSimilarity = 2
     LogCosineSimilarity = 3
     CosineSimilarityNoSourceEmbeddingNormalization = 4
+    # the offline all-users job's scores (scio/bq_generation/sql/tweets_ann.sql:44-52): not thrift values
+    OfflineLogCosineSimilarity = 5
+    OfflineCosineSimilarity = 6
 
 
 class Variant(enum.IntEnum):
@@ -140,6 +143,7 @@ _PROTOS = {
     "sann_version": (C.c_char_p, []),
     "sann_runtime_advice": (C.c_char_p, []),
     "sann_index_build": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "sann_index_build_with_norms": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "sann_index_build_synthetic": (C.c_int, [C.POINTER(sann_index_options_t), C.POINTER(sann_synth_params_t), C.POINTER(C.c_void_p)]),
     "sann_synth_tweet_embeddings": (C.c_int, [C.c_int32, C.POINTER(sann_synth_params_t), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sann_synth_exact_cosine_topk": (C.c_int, [C.c_int32, C.POINTER(sann_synth_params_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -237,7 +241,9 @@ class ClusterTweetIndex:
     descending and capped, exactly as the reference store returns them."""
 
     def __init__(self, cluster_ids, list_offsets, tweet_ids, scores, *, device: int = 0, n_partitions: int = 0,
-                 shard_id: int = 0, n_shards: int = 1):
+                 shard_id: int = 0, n_shards: int = 1, tweet_norms=None):
+        """tweet_norms (optional, one per posting): the tweet's full-embedding sum of squares, for the offline job's
+        scores (sann_index_build_with_norms)."""
         lib = load_library()
         self.cluster_ids = np.ascontiguousarray(cluster_ids, dtype=np.int32)
         self.list_offsets = np.ascontiguousarray(list_offsets, dtype=np.int64)
@@ -245,8 +251,14 @@ class ClusterTweetIndex:
         scores = np.ascontiguousarray(scores, dtype=np.float64)
         opts = sann_index_options_t(device, n_partitions, shard_id, n_shards)
         h = C.c_void_p()
-        _check(lib.sann_index_build(C.byref(opts), len(self.cluster_ids), _ptr(self.cluster_ids), _ptr(self.list_offsets),
-                                    _ptr(tweet_ids), _ptr(scores), C.byref(h)))
+        if tweet_norms is None:
+            _check(lib.sann_index_build(C.byref(opts), len(self.cluster_ids), _ptr(self.cluster_ids), _ptr(self.list_offsets),
+                                        _ptr(tweet_ids), _ptr(scores), C.byref(h)))
+        else:
+            norms = np.ascontiguousarray(tweet_norms, dtype=np.float64)
+            assert norms.shape == scores.shape
+            _check(lib.sann_index_build_with_norms(C.byref(opts), len(self.cluster_ids), _ptr(self.cluster_ids),
+                                                   _ptr(self.list_offsets), _ptr(tweet_ids), _ptr(scores), _ptr(norms), C.byref(h)))
         self._h = h
         self.device = device
 
