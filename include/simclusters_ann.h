@@ -148,6 +148,23 @@ int sann_index_build_with_norms(const sann_index_options_t *opts, int32_t n_list
                                 const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores,
                                 const double *tweet_norms, sann_index_t **out);
 /*
+ * The posting-list provider itself, on the device: RAW store entries in, index out.  Per cluster
+ * the store holds a map tweet -> DecayedValue(value, scaledTime) (scaledTime = ms * ln 2 / halfLife, 8 h in
+ * summingbird/common/Configs.scala:38); what the operator receives is
+ *   decay every value to now   summingbird/stores/TopKTweetsForClusterReadableStore.scala:51-71, EntityUtil.scala:10-28,
+ *                              ThriftDecayedValueMonoid.scala:33-38 (algebird DecayedValueMonoid(0.0).plus with a zero at now)
+ *   keep value > 0.0, sort by value descending, take(max_results)   TopKTweetsForClusterReadableStore.scala:211-229,258-259
+ * and that is what this builds -- one workgroup per cluster: decay + filter at load, LDS bitonic sort under the total
+ * order (value desc, tweet id asc), cap, tweet-hash partition.  scaled_times == NULL skips the decay (the Manhattan
+ * read-only store, :236-260).  Lists of more than 4096 raw entries are refused (SANN_ELIMIT; the store keeps <= 1.2 x
+ * topK = 1920: summingbird/common/Monoids.scala:440-449); a tweet id twice in one list is refused (SANN_EINVAL).
+ * exp is fdlibm's (java.lang.StrictMath.exp); HotSpot's Math.exp may differ from it in the last ulp.
+ */
+int sann_index_build_from_postings(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
+                                   const int64_t *list_offsets, const int64_t *tweet_ids, const double *values,
+                                   const double *scaled_times, int64_t now_ms, int64_t half_life_ms, int32_t max_results,
+                                   sann_index_t **out);
+/*
  * Generate the synthetic SimClusters corpus of SURVEY.md section 8(d) on the device and build
  * the index from it without a host round trip (per-cluster filter -> sort by score descending
  * -> cap -> partition: the device form of TopKTweetsForClusterReadableStore.scala:211-229).

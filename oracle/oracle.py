@@ -312,5 +312,27 @@ def tweets_ann_sql(consumer_embeddings, tweet_embeddings, top_n, top_m, top_k):
     return out
 
 
+def strict_exp(x: float) -> float:
+    L = lib()
+    L.oracle_strict_exp.restype = C.c_double
+    L.oracle_strict_exp.argtypes = [C.c_double]
+    return float(L.oracle_strict_exp(float(x)))
+
+
+def store_list(tweet_ids, values, scaled_times, now_scaled, max_results):
+    """One cluster's posting list as TopKTweetsForClusterReadableStore + the provider return it: decay to now,
+    keep > 0, sort by score descending (ties tweet id ascending), take."""
+    L = lib()
+    L.oracle_store_list.restype = C.c_int32
+    L.oracle_store_list.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]
+    t = np.ascontiguousarray(tweet_ids, np.int64)
+    v = np.ascontiguousarray(values, np.float64)
+    st = None if scaled_times is None else np.ascontiguousarray(scaled_times, np.float64)
+    out_i = np.zeros(len(t) + 1, np.int64)
+    out_s = np.zeros(len(t) + 1, np.float64)
+    m = L.oracle_store_list(len(t), _p(t), _p(v), _p(st), float(now_scaled), int(max_results), _p(out_i), _p(out_s))
+    return out_i[:m].copy(), out_s[:m].copy()
+
+
 def strict_log(x: float) -> float:
     return float(lib().oracle_strict_log(float(x)))

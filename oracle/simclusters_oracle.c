@@ -509,6 +509,87 @@ int32_t oracle_sann_query(int32_t variant, int32_t n_emb, const int32_t *emb_ids
   return nres;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Posting-list materialisation: what the cluster -> top tweets store hands the operator.
+ *   decay to now     summingbird/stores/TopKTweetsForClusterReadableStore.scala:51-71 -> summingbird/common/EntityUtil.scala:10-28
+ *                    -> ThriftDecayedValueMonoid.decayToTimestamp (summingbird/common/ThriftDecayedValueMonoid.scala:33-38)
+ *                    = algebird DecayedValueMonoid(eps 0.0).plus(v, DecayedValue(0.0, now * ln2 / halfLife))
+ *                    (com.twitter.algebird: not vendored, no version pinned in the tree; restated from its published
+ *                    DecayedValue: scaledPlus(newer, older) = newer.value + exp(older.t - newer.t) * older.value)
+ *   filter / sort    TopKTweetsForClusterReadableStore.scala:211-229: value > 0.0, .toSeq.sortBy(-_._2)
+ *                    (ties: Map iteration order under a stable sort -- fixed here as tweet id ascending)
+ *   take             :258-259, :281-282  .take(maxResults)
+ * math.exp is restated as fdlibm's __ieee754_exp (= StrictMath.exp); HotSpot's Math.exp may differ by 1 ulp.
+ * ---------------------------------------------------------------------------------------- */
+double oracle_strict_exp(double x) {
+  static const double halF[2] = {0.5, -0.5}, huge = 1.0e+300, twom1000 = 9.33263618503218878990e-302,
+                      o_threshold = 7.09782712893383973096e+02, u_threshold = -7.45133219101941108420e+02,
+                      ln2HI[2] = {6.93147180369123816490e-01, -6.93147180369123816490e-01},
+                      ln2LO[2] = {1.90821492927058770002e-10, -1.90821492927058770002e-10},
+                      invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                      P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                      P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  double y, hi = 0.0, lo = 0.0, c, t;
+  int32_t k = 0, xsb;
+  uint32_t hx = (uint32_t)hi_word(x);
+  xsb = (int32_t)((hx >> 31) & 1);
+  hx &= 0x7fffffff;
+  if (hx >= 0x40862E42) {
+    if (hx >= 0x7ff00000) {
+      if (((hx & 0xfffff) | lo_word(x)) != 0) return x + x;
+      return (xsb == 0) ? x : 0.0;
+    }
+    if (x > o_threshold) return huge * huge;
+    if (x < u_threshold) return twom1000 * twom1000;
+  }
+  if (hx > 0x3fd62e42) {
+    if (hx < 0x3FF0A2B2) {
+      hi = x - ln2HI[xsb];
+      lo = ln2LO[xsb];
+      k = 1 - xsb - xsb;
+    } else {
+      k = (int32_t)(invln2 * x + halF[xsb]);
+      t = k;
+      hi = x - t * ln2HI[0];
+      lo = t * ln2LO[0];
+    }
+    x = hi - lo;
+  } else if (hx < 0x3e300000) {
+    return 1.0 + x;
+  }
+  t = x * x;
+  c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+  y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+  if (k >= -1021) return with_hi(y, hi_word(y) + (k << 20));
+  y = with_hi(y, hi_word(y) + ((k + 1000) << 20));
+  return y * twom1000;
+}
+
+double oracle_decay_to_timestamp(double value, double scaled_time, double now_scaled) {
+  double nv = scaled_time < now_scaled ? 0.0 + oracle_strict_exp(scaled_time - now_scaled) * value
+                                       : value + oracle_strict_exp(now_scaled - scaled_time) * 0.0;
+  return fabs(nv) > 0.0 ? nv : 0.0;
+}
+
+/* One cluster's list as the store returns it.  scaled_times may be NULL (a store that does not decay: the
+ * Manhattan read-only path, :236-260).  Returns the number of (tweet, score) pairs written (<= max_results). */
+int32_t oracle_store_list(int32_t n, const int64_t *tweet_ids, const double *values, const double *scaled_times,
+                          double now_scaled, int32_t max_results, int64_t *out_ids, double *out_scores) {
+  scored *v = malloc(sizeof(scored) * (size_t)(n + 1));
+  int32_t m = 0;
+  for (int32_t i = 0; i < n; i++) {
+    double x = scaled_times ? oracle_decay_to_timestamp(values[i], scaled_times[i], now_scaled) : values[i];
+    if (x > 0.0) { v[m].id = tweet_ids[i]; v[m].score = x; m++; }
+  }
+  qsort(v, (size_t)m, sizeof(scored), cmp_scored); /* sortBy(-score), ties tweet id ascending */
+  if (max_results < 0) max_results = 0;
+  if (m > max_results) m = max_results;
+  for (int32_t i = 0; i < m; i++) { out_ids[i] = v[i].id; out_scores[i] = v[i].score; }
+  free(v);
+  return m;
+}
+
 /* Exact cosine of the source embedding against a tweet's FULL embedding -- what SANN
  * approximates (simclusters-ann/README.md:18-46); used for the quality recall@k only. */
 double oracle_full_cosine(int32_t n1, const int32_t *ids1, const double *sc1, int32_t n2,

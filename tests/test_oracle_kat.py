@@ -109,3 +109,33 @@ def test_baseline_legs_equal_the_oracle(oracle):
                 a = oracle.baseline_query(variant, e_i, e_s, Cfg, co.now_ms, co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores)
                 b = oracle.sann_query(e_i, e_s, None, Cfg, co.now_ms, co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, variant=variant)
                 assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.int64), b[1].view(np.int64))
+
+
+def test_strict_exp_is_within_an_ulp_of_libm(oracle):
+    import math
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(-40, 5, 20000), rng.uniform(-1e-3, 1e-3, 2000), [0.0, -0.0, 1.0, -1.0, 709.0, -745.0, -750.0, 710.0]])
+    for x in xs:
+        got, want = oracle.strict_exp(float(x)), math.exp(float(x)) if x < 709.7 else float("inf")
+        assert got == want or abs(got - want) <= math.ulp(want), (x, got, want)
+    assert oracle.strict_exp(float("-inf")) == 0.0 and oracle.strict_exp(float("inf")) == float("inf")
+
+
+def test_store_list_hand_cases(oracle):
+    """TopKTweetsForClusterReadableStore + provider on values a reader can check: half-life decay, the > 0 filter,
+    score-descending order with id-ascending ties, take."""
+    import math
+    half_life = 8 * 3600 * 1000
+    now = 1_700_000_000_000
+    sc = lambda ms: ms * math.log(2.0) / half_life  # DecayedValue.build's scaledTime
+    ids = np.array([5, 6, 7, 8, 9, 10], np.int64)
+    vals = np.array([1.0, 4.0, 2.0, 0.0, -3.0, 2.0])
+    #        8 h old -> 0.5 | 16 h old -> 1.0 | now -> 2.0 | zero | negative | written 1 h in the FUTURE: kept as is
+    st = np.array([sc(now - half_life), sc(now - 2 * half_life), sc(now), sc(now), sc(now), sc(now + 3600_000)])
+    got_i, got_s = oracle.store_list(ids, vals, st, sc(now), 10)
+    assert got_i.tolist() == [7, 10, 6, 5]  # 2.0 (id 7) and 2.0 (id 10) tie: id ascending
+    assert got_s[0] == 2.0 and got_s[1] == 2.0
+    # (scaledTime ~ 4e4 carries ~7e-12 of rounding: the decay factor is exact to about 1e-11, as in the reference)
+    assert abs(got_s[2] - 1.0) <= 1e-10 and abs(got_s[3] - 0.5) <= 1e-10
+    assert oracle.store_list(ids, vals, st, sc(now), 2)[0].tolist() == [7, 10]          # take(2)
+    assert oracle.store_list(ids, vals, None, 0.0, 10)[0].tolist() == [6, 7, 10, 5]    # no decay: 4, 2, 2, 1

@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "sann_host.h"
+#include "sann_math.h"
 
 using namespace sann;
 using sann_host::DevBuf;
@@ -191,11 +192,16 @@ __global__ __launch_bounds__(256) void exact_cosine_kernel(GenParams g, int nq, 
 }
 
 // One workgroup per cluster id c in [1, C]: sort the bucket, cap, count per partition.
+// scaled != NULL: the buckets hold RAW store entries (value, with scaled[i] = its DecayedValue.scaledTime): every value is
+// first decayed to now_scaled (decay_to_timestamp, sann_math.h) and entries that are not > 0 afterwards are dropped --
+// TopKTweetsForClusterReadableStore.scala:51-71 and :222-223 -- before the sort (:227) and the cap (:258-259).
 __global__ __launch_bounds__(256) void sort_kernel(int n_clusters, int index_cap, int P, int n_shards, int shard_id,
                                                    const uint32_t *bucket_off, const uint32_t *cursor, Posting *buckets,
-                                                   uint32_t *kept /*[C+1]*/, uint32_t *cnt_cp /*[C*P]*/) {
+                                                   uint32_t *kept /*[C+1]*/, uint32_t *cnt_cp /*[C*P]*/,
+                                                   const double *scaled, double now_scaled, int filter_positive) {
   __shared__ uint64_t s_hi[SORT_MAX], s_lo[SORT_MAX];
   __shared__ unsigned s_cnt[256];
+  __shared__ unsigned s_valid;
   const int c = blockIdx.x + 1;
   const int tid = threadIdx.x;
   const uint32_t base = bucket_off[c];
@@ -204,18 +210,28 @@ __global__ __launch_bounds__(256) void sort_kernel(int n_clusters, int index_cap
   if (n > cap) n = cap;
   int np = 2;
   while (np < (int)n) np <<= 1;
-  for (int i = tid; i < np; i += 256) {
-    if (i < (int)n) {
-      const Posting p = buckets[base + i];
-      s_hi[i] = score_key(p.score);
-      s_lo[i] = id_key(p.id);
-    } else {
-      s_hi[i] = 0;
-      s_lo[i] = 0;
-    }
-  }
+  if (tid == 0) s_valid = 0;
   for (int i = tid; i < 256; i += 256) s_cnt[i] = 0;
   __syncthreads();
+  unsigned mine = 0;
+  for (int i = tid; i < np; i += 256) {
+    uint64_t hi = 0, lo = 0;  // (sorts behind every kept entry: a positive score's key has the top bit set)
+    if (i < (int)n) {
+      const Posting p = buckets[base + i];
+      double v = p.score;
+      if (scaled) v = decay_to_timestamp(v, scaled[base + i], now_scaled);
+      if (!filter_positive || v > 0.0) {
+        hi = score_key(v);
+        lo = id_key(p.id);
+        mine++;
+      }
+    }
+    s_hi[i] = hi;
+    s_lo[i] = lo;
+  }
+  if (mine) atomicAdd(&s_valid, mine);
+  __syncthreads();
+  n = s_valid;
   for (int size = 2; size <= np; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int t = tid; t < (np >> 1); t += 256) {
@@ -440,7 +456,7 @@ int sann_index_build_synthetic(const sann_index_options_t *opts, const sann_synt
   // ---- 3. sort + cap + count ----------------------------------------------------------------------
   hipLaunchKernelGGL(sort_kernel, dim3((unsigned)C), dim3(256), 0, 0, C, sp->index_cap, P, n_shards, ix->shard_id,
                      d_boff.as<uint32_t>(), d_cursor.as<uint32_t>(), d_buckets.as<Posting>(), d_kept.as<uint32_t>(),
-                     d_cnt.as<uint32_t>());
+                     d_cnt.as<uint32_t>(), (const double *)nullptr, 0.0, 0);
   HIP_TRY(hipGetLastError());
   std::vector<uint32_t> cnt((size_t)C * P), kept((size_t)C + 1);
   HIP_TRY(hipMemcpy(cnt.data(), d_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
@@ -474,6 +490,125 @@ int sann_index_build_synthetic(const sann_index_options_t *opts, const sann_synt
                      d_kept.as<uint32_t>(), d_buckets.as<Posting>(), ix->sub_offsets.as<uint32_t>(),
                      ix->postings.as<Posting>(), ix->ranks.as<uint32_t>());
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  guard.p = nullptr;
+  *out = ix;
+  return SANN_OK;
+}
+
+// The cluster -> top tweets provider on the device: raw store entries in, index out.
+int sann_index_build_from_postings(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
+                                   const int64_t *list_offsets, const int64_t *tweet_ids, const double *values,
+                                   const double *scaled_times, int64_t now_ms, int64_t half_life_ms, int32_t max_results,
+                                   sann_index_t **out) {
+  if (!out) return fail(SANN_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (!opts) return fail(SANN_EINVAL, "opts is NULL");
+  if (n_lists < 0 || (n_lists > 0 && (!cluster_ids || !list_offsets))) return fail(SANN_EINVAL, "bad list arrays");
+  const int P = opts->n_partitions == 0 ? 32 : opts->n_partitions;
+  if (P < 1 || P > 128 || (P & (P - 1))) return fail(SANN_EINVAL, "n_partitions must be a power of two in [1,128]");
+  const int n_shards = opts->n_shards <= 0 ? 1 : opts->n_shards;
+  if (opts->shard_id < 0 || opts->shard_id >= n_shards) return fail(SANN_EINVAL, "shard_id out of range");
+  if (max_results < 0) max_results = 0;
+  if (scaled_times && half_life_ms <= 0) return fail(SANN_EINVAL, "half_life_ms must be positive");
+  for (int32_t i = 1; i < n_lists; i++)
+    if (cluster_ids[i] <= cluster_ids[i - 1]) return fail(SANN_EINVAL, "cluster_ids must be ascending and unique");
+  const int64_t o0 = n_lists ? list_offsets[0] : 0;
+  int64_t total = 0;
+  {
+    std::vector<int64_t> tmp;
+    for (int32_t r = 0; r < n_lists; r++) {
+      const int64_t len = list_offsets[r + 1] - list_offsets[r];
+      if (len < 0) return fail(SANN_EINVAL, "list_offsets must be non-decreasing");
+      if (len > SORT_MAX) return fail(SANN_ELIMIT, "a raw list holds more than 4096 entries (the store keeps <= 1.2 x 1600: Monoids.scala:440-449)");
+      total += len;
+      if (len >= 2) {  // keys of a Map in the store: unique
+        tmp.assign(tweet_ids + list_offsets[r], tweet_ids + list_offsets[r + 1]);
+        std::sort(tmp.begin(), tmp.end());
+        if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end())
+          return fail(SANN_EINVAL, "cluster " + std::to_string(cluster_ids[r]) + ": a tweet id appears twice in one list");
+      }
+    }
+  }
+  if (total > 0xfffffff0ll) return fail(SANN_ELIMIT, "more than 2^32 raw postings");
+  if (total > 0 && (!tweet_ids || !values)) return fail(SANN_EINVAL, "tweet_ids/values are NULL");
+  const int C = n_lists;
+
+  sann_index *ix = new (std::nothrow) sann_index();
+  if (!ix) return fail(SANN_ENOMEM, "out of host memory");
+  struct Guard { sann_index *p; ~Guard() { delete p; } } guard{ix};
+  ix->device = opts->device;
+  ix->P = P;
+  ix->log2P = 0;
+  while ((1 << ix->log2P) < P) ix->log2P++;
+  ix->shard_id = opts->shard_id;
+  ix->n_shards = n_shards;
+  ix->cluster_ids.assign(cluster_ids, cluster_ids + C);
+
+  // buckets = the raw lists as given (1-based cluster slots, as the kernels index them)
+  std::vector<uint32_t> boff((size_t)C + 2, 0), cursor((size_t)C + 1, 0);
+  for (int c = 1; c <= C; c++) {
+    boff[(size_t)c] = (uint32_t)(list_offsets[c - 1] - o0);
+    cursor[(size_t)c] = (uint32_t)(list_offsets[c] - list_offsets[c - 1]);
+  }
+  boff[(size_t)C + 1] = (uint32_t)total;
+  std::vector<Posting> raw((size_t)total);
+  for (int64_t i = 0; i < total; i++) { raw[(size_t)i].id = tweet_ids[o0 + i]; raw[(size_t)i].score = values[o0 + i]; }
+
+  HIP_TRY(hipSetDevice(ix->device));
+  DevBuf d_boff, d_cursor, d_buckets, d_scaled, d_kept, d_cnt;
+  HIP_TRY(d_boff.alloc(boff.size() * 4));
+  HIP_TRY(d_cursor.alloc(cursor.size() * 4));
+  HIP_TRY(d_kept.alloc(((size_t)C + 1) * 4));
+  HIP_TRY(d_cnt.alloc(std::max<size_t>((size_t)C * P, 1) * 4));
+  HIP_TRY(d_buckets.alloc(std::max<size_t>((size_t)total, 1) * sizeof(Posting)));
+  HIP_TRY(hipMemcpy(d_boff.p, boff.data(), boff.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_cursor.p, cursor.data(), cursor.size() * 4, hipMemcpyHostToDevice));
+  if (total) HIP_TRY(hipMemcpy(d_buckets.p, raw.data(), (size_t)total * sizeof(Posting), hipMemcpyHostToDevice));
+  if (scaled_times && total) {
+    HIP_TRY(d_scaled.alloc((size_t)total * 8));
+    HIP_TRY(hipMemcpy(d_scaled.p, scaled_times + o0, (size_t)total * 8, hipMemcpyHostToDevice));
+  }
+  // DecayedValue.build(0.0, now, halfLife).scaledTime = now * math.log(2.0) / halfLife  (algebird; log(2.0) = M_LN2 exactly)
+  const double now_scaled = scaled_times ? (double)now_ms * 0.69314718055994530942 / (double)half_life_ms : 0.0;
+
+  if (C > 0) {
+    hipLaunchKernelGGL(sort_kernel, dim3((unsigned)C), dim3(256), 0, 0, C, max_results, P, n_shards, ix->shard_id,
+                       d_boff.as<uint32_t>(), d_cursor.as<uint32_t>(), d_buckets.as<Posting>(), d_kept.as<uint32_t>(),
+                       d_cnt.as<uint32_t>(), d_scaled.as<double>(), now_scaled, 1);
+    HIP_TRY(hipGetLastError());
+  }
+  std::vector<uint32_t> cnt((size_t)C * P), kept((size_t)C + 1, 0);
+  if (C > 0) {
+    HIP_TRY(hipMemcpy(cnt.data(), d_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(kept.data(), d_kept.p, kept.size() * 4, hipMemcpyDeviceToHost));
+  }
+  ix->h_sub_offsets.resize((size_t)C * P + 1);
+  uint64_t tot = 0;
+  for (size_t i = 0; i < (size_t)C * P; i++) {
+    ix->h_sub_offsets[i] = (uint32_t)tot;
+    tot += cnt[i];
+  }
+  ix->h_sub_offsets[(size_t)C * P] = (uint32_t)tot;
+  ix->n_postings = (int64_t)tot;
+  int64_t total_all = 0;
+  int32_t max_len = 0;
+  for (int c = 1; c <= C; c++) {
+    total_all += kept[(size_t)c];
+    max_len = std::max<int32_t>(max_len, (int32_t)kept[(size_t)c]);
+  }
+  ix->n_postings_total = total_all;
+  ix->max_list_len = max_len;
+  HIP_TRY(ix->postings.alloc(std::max<uint64_t>(tot, 1) * sizeof(Posting)));
+  HIP_TRY(ix->ranks.alloc(std::max<uint64_t>(tot, 1) * 4));
+  HIP_TRY(ix->sub_offsets.alloc(ix->h_sub_offsets.size() * 4));
+  HIP_TRY(hipMemcpy(ix->sub_offsets.p, ix->h_sub_offsets.data(), ix->h_sub_offsets.size() * 4, hipMemcpyHostToDevice));
+  if (C > 0) {
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)C), dim3(256), 0, 0, P, n_shards, ix->shard_id, d_boff.as<uint32_t>(),
+                       d_kept.as<uint32_t>(), d_buckets.as<Posting>(), ix->sub_offsets.as<uint32_t>(),
+                       ix->postings.as<Posting>(), ix->ranks.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipDeviceSynchronize());
   guard.p = nullptr;
   *out = ix;

@@ -94,6 +94,65 @@ SANN_HD inline double strict_log(double x) {
   return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
 }
 
+// math.exp as java.lang.StrictMath.exp specifies it: the fdlibm __ieee754_exp algorithm (argument reduction
+// x = k ln2 + r, |r| <= 0.5 ln2; exp(r) from the degree-5 Remez approximation of r (exp(r)+1)/(exp(r)-1); scaling by 2^k).
+// Used to decay posting scores to "now" (algebird DecayedValueMonoid.scaledPlus, called from
+// summingbird/common/ThriftDecayedValueMonoid.scala:33-38).  HotSpot's Math.exp intrinsic may differ by 1 ulp.
+SANN_HD inline double strict_exp(double x) {
+  const double o_threshold = 7.09782712893383973096e+02, u_threshold = -7.45133219101941108420e+02;
+  const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+               P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  const double huge = 1.0e+300, twom1000 = 9.33263618503218878990e-302;
+  uint64_t u = f64_bits(x);
+  uint32_t hx = (uint32_t)(u >> 32);
+  const int xsb = (int)((hx >> 31) & 1u);
+  hx &= 0x7fffffffu;
+  double hi = 0.0, lo = 0.0;
+  int k = 0;
+  if (hx >= 0x40862E42u) {  // |x| >= 709.78...
+    if (hx >= 0x7ff00000u) {
+      if (((hx & 0xfffffu) | (uint32_t)u) != 0) return x + x;  // NaN
+      return xsb == 0 ? x : 0.0;                                // exp(+-inf) = {inf, 0}
+    }
+    if (x > o_threshold) return huge * huge;
+    if (x < u_threshold) return twom1000 * twom1000;
+  }
+  if (hx > 0x3fd62e42u) {  // |x| > 0.5 ln2
+    if (hx < 0x3FF0A2B2u) {  // and |x| < 1.5 ln2
+      hi = xsb ? x + ln2HI : x - ln2HI;
+      lo = xsb ? -ln2LO : ln2LO;
+      k = 1 - xsb - xsb;
+    } else {
+      k = (int)(invln2 * x + (xsb ? -0.5 : 0.5));
+      const double t = (double)k;
+      hi = x - t * ln2HI;
+      lo = t * ln2LO;
+    }
+    x = hi - lo;
+  } else if (hx < 0x3e300000u) {  // |x| < 2^-28
+    return 1.0 + x;
+  }
+  const double t = x * x;
+  const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+  double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+  if (k >= -1021) return bits_f64(f64_bits(y) + ((uint64_t)(uint32_t)k << 52));
+  y = bits_f64(f64_bits(y) + ((uint64_t)(uint32_t)(k + 1000) << 52));
+  return y * twom1000;
+}
+
+// algebird DecayedValueMonoid(eps = 0.0).plus(v, DecayedValue(0.0, now)) -- what
+// ThriftDecayedValueMonoid.decayToTimestamp (summingbird/common/ThriftDecayedValueMonoid.scala:33-38, built with
+// Implicits.scala:28 eps 0.0) does to a posting's (value, scaledTime), scaledTime = ms * ln 2 / halfLife:
+//   scaledPlus(newer, older) = newer.value + exp(older.scaledTime - newer.scaledTime) * older.value, zero unless |.| > eps
+// (com.twitter.algebird is not vendored and no version is pinned in the tree; this is its published DecayedValue.)
+SANN_HD inline double decay_to_timestamp(double value, double scaled_time, double now_scaled) {
+  const double nv = scaled_time < now_scaled ? 0.0 + strict_exp(scaled_time - now_scaled) * value
+                                             : value + strict_exp(now_scaled - scaled_time) * 0.0;
+  return (nv > 0.0 || nv < 0.0) ? nv : 0.0;
+}
+
 // Monotone map double -> uint64 that realises java.lang.Double.compare order
 // (-0.0 < +0.0; NaNs never reach it: they fail `score >= minScore`).
 SANN_HD inline uint64_t score_key(double s) {

@@ -144,6 +144,7 @@ _PROTOS = {
     "sann_runtime_advice": (C.c_char_p, []),
     "sann_index_build": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "sann_index_build_with_norms": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "sann_index_build_from_postings": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "sann_index_build_synthetic": (C.c_int, [C.POINTER(sann_index_options_t), C.POINTER(sann_synth_params_t), C.POINTER(C.c_void_p)]),
     "sann_synth_tweet_embeddings": (C.c_int, [C.c_int32, C.POINTER(sann_synth_params_t), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sann_synth_exact_cosine_topk": (C.c_int, [C.c_int32, C.POINTER(sann_synth_params_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -261,6 +262,27 @@ class ClusterTweetIndex:
                                                    _ptr(self.list_offsets), _ptr(tweet_ids), _ptr(scores), _ptr(norms), C.byref(h)))
         self._h = h
         self.device = device
+
+    @classmethod
+    def from_raw_postings(cls, cluster_ids, list_offsets, tweet_ids, values, scaled_times, *, now_ms: int,
+                          half_life_ms: int = 8 * 3600 * 1000, max_results: int = 2000, device: int = 0, n_partitions: int = 0,
+                          shard_id: int = 0, n_shards: int = 1) -> "ClusterTweetIndex":
+        """sann_index_build_from_postings: the store's raw (tweet, value, scaledTime) entries -> decay to now, keep > 0,
+        sort descending, take(max_results), partition -- on the device."""
+        lib = load_library()
+        self = cls.__new__(cls)
+        self.cluster_ids = np.ascontiguousarray(cluster_ids, dtype=np.int32)
+        self.list_offsets = np.ascontiguousarray(list_offsets, dtype=np.int64)
+        t = np.ascontiguousarray(tweet_ids, dtype=np.int64)
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        st = None if scaled_times is None else np.ascontiguousarray(scaled_times, dtype=np.float64)
+        opts = sann_index_options_t(device, n_partitions, shard_id, n_shards)
+        h = C.c_void_p()
+        _check(lib.sann_index_build_from_postings(C.byref(opts), len(self.cluster_ids), _ptr(self.cluster_ids), _ptr(self.list_offsets),
+                                                  _ptr(t), _ptr(v), _ptr(st), int(now_ms), int(half_life_ms), int(max_results), C.byref(h)))
+        self._h = h
+        self.device = device
+        return self
 
     @classmethod
     def synthetic(cls, n_tweets: int, n_clusters: int = 144_428, *, seed: int = 20260104, index_cap: int = 2000,
