@@ -336,3 +336,98 @@ def store_list(tweet_ids, values, scaled_times, now_scaled, max_results):
 
 def strict_log(x: float) -> float:
     return float(lib().oracle_strict_log(float(x)))
+
+
+# ---------------------------------------------------------------------------------------------
+# representation-scorer `simClustersRecentEngagementSimilarity`: the whole feature computation from RAW user signals,
+# restated literally and independently of the product's Engagements mirror (round-1 review: the test fed the oracle the
+# product's own window grouping).  Paths relative to /root/reference/representation-scorer/server/src/main/scala/com/
+# twitter/representationscorer/twistlyfeatures/.
+# ---------------------------------------------------------------------------------------------
+_DAY_MS = 86_400_000
+# UserSignalServiceRecentEngagementsClient.scala:38-52: Engagements field <- (SignalType, earliest valid = now - days)
+_USS_FIELDS = (("favs7d", "TweetFavorite", 7), ("retweets7d", "Retweet", 7), ("follows30d", "AccountFollowWithDelay", 30),
+               ("shares7d", "TweetShareV1", 7), ("replies7d", "Reply", 7), ("originalTweets7d", "OriginalTweet", 7),
+               ("videoPlaybacks7d", "VideoView90dPlayback50V1", 7), ("block30d", "AccountBlock", 30),
+               ("mute30d", "AccountMute", 30), ("report30d", "TweetReport", 30), ("dontlike30d", "TweetDontLike", 30),
+               ("seeFewer30d", "TweetSeeFewer", 30))
+# Scorer.scala:306-369: SimClustersRecentEngagementSimilarities field prefix <- (Engagements value, score map), in the
+# constructor's order.  block* / mute* read the TWEET score map although their targets are authors (:232-260): restated
+# as written.
+_FEATURES = (("fav1d", "favs1d", "tweet"), ("fav7d", "favs7d", "tweet"), ("retweet1d", "retweets1d", "tweet"),
+             ("retweet7d", "retweets7d", "tweet"), ("follow7d", "follows7d", "author"), ("follow30d", "follows30d", "author"),
+             ("share1d", "shares1d", "tweet"), ("share7d", "shares7d", "tweet"), ("reply1d", "replies1d", "tweet"),
+             ("reply7d", "replies7d", "tweet"), ("originalTweet1d", "originalTweets1d", "tweet"),
+             ("originalTweet7d", "originalTweets7d", "tweet"), ("videoPlayback1d", "videoPlaybacks1d", "tweet"),
+             ("videoPlayback7d", "videoPlaybacks7d", "tweet"), ("block1d", "block1d", "tweet"), ("block7d", "block7d", "tweet"),
+             ("block30d", "block30d", "tweet"), ("mute1d", "mute1d", "tweet"), ("mute7d", "mute7d", "tweet"),
+             ("mute30d", "mute30d", "tweet"), ("report1d", "report1d", "tweet"), ("report7d", "report7d", "tweet"),
+             ("report30d", "report30d", "tweet"), ("dontlike1d", "dontlike1d", "tweet"), ("dontlike7d", "dontlike7d", "tweet"),
+             ("dontlike30d", "dontlike30d", "tweet"), ("seeFewer1d", "seeFewer1d", "tweet"), ("seeFewer7d", "seeFewer7d", "tweet"),
+             ("seeFewer30d", "seeFewer30d", "tweet"))
+
+
+def rsx_engagements_from_signals(signal_response, now_ms):
+    """UserSignalServiceRecentEngagementsClient.get / getUserSignals (:30-71) followed by the Engagements constructor
+    (Engagements.scala:21-56).  signal_response: {SignalType name: [(targetId or None, timestamp ms), ...]} in the
+    order the signal service returned them; a None target stands for a non-Long internal id (:66-67).
+    Returns {value name: [(targetId, timestamp)]} for the 12 fields and every derived window."""
+    e = {}
+    for field, signal_type, days in _USS_FIELDS:
+        earliest = now_ms - days * _DAY_MS
+        kept = [(t, ts) for t, ts in signal_response.get(signal_type, []) if ts > earliest and t is not None]  # :63-67
+        e[field] = kept[:10]  # .take(EngagementsToScore), :68 / :128
+    one_day_ago, seven_days_ago = now_ms - _DAY_MS, now_ms - 7 * _DAY_MS  # Engagements.scala:23-25
+
+    def since(xs, cut):
+        return [s for s in xs if s[1] > cut]
+    e["dontlike7d"] = since(e["dontlike30d"], seven_days_ago)  # :36-37
+    e["seeFewer7d"] = since(e["seeFewer30d"], seven_days_ago)
+    for a, b in (("favs1d", "favs7d"), ("retweets1d", "retweets7d"), ("shares1d", "shares7d"), ("replies1d", "replies7d"),
+                 ("originalTweets1d", "originalTweets7d"), ("videoPlaybacks1d", "videoPlaybacks7d"), ("dontlike1d", "dontlike7d"),
+                 ("seeFewer1d", "seeFewer7d")):  # :39-46
+        e[a] = since(e[b], one_day_ago)
+    for a, b in (("follows7d", "follows30d"), ("block7d", "block30d"), ("mute7d", "mute30d"), ("report7d", "report30d")):  # :49-52
+        e[a] = since(e[b], seven_days_ago)
+    for a, b in (("block1d", "block7d"), ("mute1d", "mute7d"), ("report1d", "report7d")):  # :54-56
+        e[a] = since(e[b], one_day_ago)
+    # :28-33
+    e["tweetIds"] = [t for f in ("favs7d", "retweets7d", "shares7d", "replies7d", "originalTweets7d", "videoPlaybacks7d",
+                                 "report30d", "dontlike30d", "seeFewer30d") for t, _ in e[f]]
+    e["authorIds"] = [t for f in ("follows30d", "block30d", "mute30d") for t, _ in e[f]]
+    return e
+
+
+def rsx_scorer_features(signal_response, now_ms, cand_emb, tweet_embeddings, author_embeddings, algorithm=2):
+    """Scorer.get for ONE candidate tweet (Scorer.scala:125-149,157-369,426-429): {feature name: Optional[float]}, 58 names.
+    cand_emb: the candidate's (ids, scores) embedding or None; *_embeddings: id -> embedding."""
+    e = rsx_engagements_from_signals(signal_response, now_ms)
+
+    def score_results(ids, embs):  # getTweetScores / getUserScores: one ScoreResult(id, Option[score]) per requested id
+        out = []
+        for i in ids:
+            s = embs.get(i)
+            out.append((i, None if cand_emb is None or s is None else pair_score(algorithm, s[0], s[1], cand_emb[0], cand_emb[1])))
+        return out
+    maps = {}
+    for name, ids, embs in (("tweet", e["tweetIds"], tweet_embeddings), ("author", e["authorIds"], author_embeddings)):
+        grouped = {}
+        for i, s in score_results(ids, embs):  # .groupBy(_.id), :141-142
+            grouped.setdefault(i, []).append(s)
+        maps[name] = grouped
+    feats = {}
+    for prefix, value, which in _FEATURES:
+        # engagements.<value>.view.flatMap(s => scores.get(s.targetId)).flatten.flatMap(_.score).force
+        vals = [s for t, _ts in e[value] for s in maps[which].get(t, []) if s is not None]
+        if not vals:
+            feats[prefix + "Last10Max"] = feats[prefix + "Last10Avg"] = None
+            continue
+        total = 0.0
+        for v in vals:  # s.sum / s.size, :427
+            total = total + v
+        mx = 0.0
+        for v in vals:  # foldLeft(0.0)(math.max), :429
+            mx = max(mx, v)
+        feats[prefix + "Last10Avg"] = total / len(vals)
+        feats[prefix + "Last10Max"] = mx
+    return feats

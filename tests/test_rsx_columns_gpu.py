@@ -92,6 +92,45 @@ def test_scorer_features_match_the_reference_fold(world, oracle):
     assert set(by_name["fav1d"]) <= set(by_name["fav7d"]) and set(by_name["block1d"]) <= set(by_name["block7d"]) <= set(by_name["block30d"])
 
 
+def test_scorer_features_from_raw_signals(world, oracle):
+    """R5 end to end from RAW user signals: the product (Engagements.from_signal_response -> windows -> device folds)
+    against oracle.rsx_scorer_features, which restates UserSignalServiceRecentEngagementsClient.getUserSignals (window
+    filter, Long ids only, take 10), Engagements.scala:21-56 and Scorer.scala:157-369 on its own -- including signals
+    exactly on a window edge (`>` is strict), more than 10 signals per type, and the block / mute map quirk."""
+    rs, rng, tweets, authors, ts, au = world
+    now = 1_700_000_000_000
+    day = 86_400_000
+    t_ids = list(tweets); a_ids = list(authors)
+
+    def raw(pool, n, span_days, edges=()):
+        out = []
+        for _ in range(n):
+            i = int(rng.choice(pool)) if rng.random() > 0.1 else int(rng.integers(20_000, 30_000))
+            out.append((i if rng.random() > 0.05 else None, now - int(rng.random() * span_days * day)))
+        out += [(int(rng.choice(pool)), now - d * day) for d in edges]          # exactly on an edge: excluded
+        out += [(int(rng.choice(pool)), now - d * day + 1) for d in edges]      # one ms inside: included
+        order = rng.permutation(len(out))
+        return [out[i] for i in order]
+
+    emb_t = {i: rs.simclusters_embedding(v) for i, v in tweets.items()}
+    emb_a = {i: rs.simclusters_embedding(v) for i, v in authors.items()}
+    for trial in range(4):
+        response = {"TweetFavorite": raw(t_ids, 18, 9, (1, 7)), "Retweet": raw(t_ids, 6, 9, (1,)),
+                    "AccountFollowWithDelay": raw(a_ids, 14, 40, (7, 30)), "TweetShareV1": raw(t_ids, 3, 8),
+                    "Reply": [] if trial % 2 else raw(t_ids, 2, 3), "OriginalTweet": raw(t_ids, 12, 8, (1,)),
+                    "VideoView90dPlayback50V1": raw(t_ids, 5, 8), "AccountBlock": raw(a_ids + t_ids[:6], 9, 35, (1, 7, 30)),
+                    "AccountMute": raw(a_ids, 4, 35), "TweetReport": raw(t_ids, 5, 35, (7,)),
+                    "TweetDontLike": raw(t_ids, 11, 35, (1, 7, 30)), "TweetSeeFewer": raw(t_ids, 2, 35)}
+        eng = rs.Engagements.from_signal_response(response, now)
+        cand_ids = [int(rng.choice(t_ids)) for _ in range(12)] + [31337]
+        got = rs.Scorer(ts, au).get(eng, cand_ids)
+        for c, feats in zip(cand_ids, got):
+            want = oracle.rsx_scorer_features(response, now, emb_t.get(c), emb_t, emb_a, algorithm=2)
+            assert set(feats) == set(want) and len(want) == 58
+            for name, w in want.items():
+                assert feats[name] == w, (trial, c, name, feats[name], w)
+
+
 def test_store_rejects_malformed_input(pkg):
     rs = pkg.representation_scorer
     lib = rs._lib()

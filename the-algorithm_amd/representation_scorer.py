@@ -163,6 +163,26 @@ class Engagements:
     dontlike30d: List[UserSignal] = field(default_factory=list)
     seeFewer30d: List[UserSignal] = field(default_factory=list)
 
+    # UserSignalServiceRecentEngagementsClient.scala:38-52: field <- (SignalType, days of validity)
+    USS_FIELDS = (("favs7d", "TweetFavorite", 7), ("retweets7d", "Retweet", 7), ("follows30d", "AccountFollowWithDelay", 30),
+                  ("shares7d", "TweetShareV1", 7), ("replies7d", "Reply", 7), ("originalTweets7d", "OriginalTweet", 7),
+                  ("videoPlaybacks7d", "VideoView90dPlayback50V1", 7), ("block30d", "AccountBlock", 30),
+                  ("mute30d", "AccountMute", 30), ("report30d", "TweetReport", 30), ("dontlike30d", "TweetDontLike", 30),
+                  ("seeFewer30d", "TweetSeeFewer", 30))
+    ENGAGEMENTS_TO_SCORE = 10  # :128
+
+    @classmethod
+    def from_signal_response(cls, signal_response, now_ms: int) -> "Engagements":
+        """UserSignalServiceRecentEngagementsClient.get / getUserSignals (:30-71): per signal type keep the signals newer
+        than the field's window whose target is a Long id, take the first 10.  signal_response: {SignalType name:
+        [(targetId or None, timestamp ms)]} as the signal service returned them."""
+        kw = {}
+        for fld, signal_type, days in cls.USS_FIELDS:
+            earliest = now_ms - days * 86_400_000
+            kept = [UserSignal(t, ts) for t, ts in signal_response.get(signal_type, []) if ts > earliest and t is not None]
+            kw[fld] = kept[:cls.ENGAGEMENTS_TO_SCORE]
+        return cls(now_ms=now_ms, **kw)
+
     def _since(self, xs, days):
         cut = self.now_ms - days * 86_400_000
         return [s for s in xs if s.timestamp > cut]
