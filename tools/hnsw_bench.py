@@ -20,22 +20,32 @@ def main():
     ap.add_argument("--dim", type=int, default=256)
     ap.add_argument("--queries", type=int, default=4096)
     ap.add_argument("--max-m", type=int, default=16)
-    ap.add_argument("--ef-construction", type=int, default=100)
+    ap.add_argument("--ef-construction", type=int, default=200)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--configs", default="10:100,200:800")
-    ap.add_argument("--clusters", type=int, default=2000, help="synthetic data: mixture of this many Gaussians")
+    ap.add_argument("--clusters", type=int, default=0, help="synthetic data: 0 = i.i.d. N(0,1) (SURVEY 8d), n = mixture of n Gaussians")
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--cpu-queries", type=int, default=32, help="queries of the CPU leg (0 = skip)")
     a = ap.parse_args()
     pkg = load_package()
     m = pkg.dense_ann.DistanceMetric.Cosine
     rng = np.random.default_rng(0)
-    centres = rng.standard_normal((a.clusters, a.dim)).astype(np.float32)
-    x = centres[rng.integers(0, a.clusters, a.vectors)] + 0.6 * rng.standard_normal((a.vectors, a.dim)).astype(np.float32)
-    q = centres[rng.integers(0, a.clusters, a.queries)] + 0.6 * rng.standard_normal((a.queries, a.dim)).astype(np.float32)
+    if a.clusters > 0:
+        centres = rng.standard_normal((a.clusters, a.dim)).astype(np.float32)
+        x = centres[rng.integers(0, a.clusters, a.vectors)] + 0.6 * rng.standard_normal((a.vectors, a.dim)).astype(np.float32)
+        q = centres[rng.integers(0, a.clusters, a.queries)] + 0.6 * rng.standard_normal((a.queries, a.dim)).astype(np.float32)
+    else:
+        x = rng.standard_normal((a.vectors, a.dim)).astype(np.float32)
+        q = rng.standard_normal((a.queries, a.dim)).astype(np.float32)
     t0 = time.time()
     ix = pkg.hnsw_ann.Hnsw.build(m, x, max_m=a.max_m, ef_construction=a.ef_construction, seed=1, n_threads=a.threads)
     build_s = time.time() - t0
     bf = pkg.dense_ann.BruteForceIndex.build(m, x)
+    # CPU leg: the reference's walk (HnswIndex.searchKnn, restated in oracle/hnsw_oracle.c) over the SAME graph, one
+    # thread, a bounded sample of the queries; also checks that the device results of those queries are the oracle's
+    from __graft_entry__ import load_oracle
+    oracle = load_oracle()
+    graph = stored = None
     for cfg in a.configs.split(","):
         k, ef = (int(v) for v in cfg.split(":"))
         ix.search(q[:64], k, ef)
@@ -47,6 +57,21 @@ def main():
         nt = min(256, a.queries)
         t_ids, _, _ = bf.search(q[:nt], k)
         recall = float(np.mean([len(set(ids[i, :cnt[i]].tolist()) & set(t_ids[i].tolist())) / k for i in range(nt)]))
+        n_cpu = min(a.cpu_queries, a.queries)
+        cpu = None
+        if n_cpu > 0:
+            if graph is None:
+                graph, stored = ix.graph(), ix.stored_vectors()
+            pq = oracle.dense_prepare(int(m), q[:n_cpu])
+            t0 = time.time()
+            same = True
+            for qi in range(n_cpu):
+                o_items, o_dist, _ = oracle.hnsw_search(int(m), stored, graph, pq[qi], k, ef)
+                same &= bool(np.array_equal(o_items, ids[qi, :cnt[qi]]))
+            cpu_s = time.time() - t0
+            cpu = {"value": n_cpu / cpu_s, "unit": "queries/s", "cores": 1, "kind": "port",
+                   "sample": f"the first {n_cpu} queries through the C restatement of HnswIndex.searchKnn on the same graph, one thread, "
+                             f"{cpu_s:.2f} s; device results identical: {same}"}
         row_bytes = ((a.dim + 63) // 64 * 64) * 2
         print(json.dumps({
             "metric": "hnsw queries/sec", "value": a.queries / wall, "unit": "queries/s",
@@ -58,6 +83,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": st["distance_evals"] * row_bytes / (st["kernel_ms"] * 1e-3) / 1e9, "peak": 8000.0,
                          "unit": "GB/s", "frac": st["distance_evals"] * row_bytes / (st["kernel_ms"] * 1e-3) / 8e12,
                          "note": "random 512-B row gathers; latency-bound walk"},
+            "cpu_baseline": cpu,
             "spilled_queries": st["spilled_queries"], "build_s": build_s, "build_threads": a.threads}), flush=True)
     ix.close(); bf.close()
 
