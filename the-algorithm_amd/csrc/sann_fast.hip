@@ -9,33 +9,39 @@
 //               threads wide, keeps that chain out of the unit kernel, whose own chain is then just
 //               descriptors -> postings.
 //
-// unit_fast_kernel   one workgroup = one unit; the unit's postings live in REGISTERS (U per
-//               thread).  The kernel is instruction-bound, not memory-bound (PMC: ~2 VMEM reads per
-//               wave), so everything is arranged to spend few instructions per posting:
-//   1. descriptors  coalesced read of the unit's (start, len) row; exclusive scan -> flat index
-//   2. gather       flat posting index -> (cluster, position) by binary search over the scan; one
-//                   16-B global load per posting, consecutive lanes = consecutive postings of a
-//                   sub-list; age window and source-tweet filters (:90-91)
-//   3. duplicates   a tweet can sit in several scanned clusters (all its postings are in this unit
-//                   by construction of the partition hash).  Each posting ORs two hash bits into
-//                   one 64-bit word of a blocked Bloom filter with ONE LDS atomic; finding both
-//                   already set flags the id as "possibly seen before".  Flagged ids (true
-//                   duplicates plus a few false positives) are matched against every thread's
-//                   registers; real groups are summed by one thread in cluster order, so fp64 sums
-//                   follow the reference's accumulation order (:83-100) whatever the timing.
-//   4. pre-filter   every live candidate gets an APPROXIMATE fp32 score (a few instructions); an
-//                   MSB-first radix histogram over the 32-bit keys, started at the highest bit in
-//                   which the unit's keys differ, finds a cut tau with between k_local and SCAP
-//                   candidates above it.  |approx/exact - 1| <= EPS, so every candidate below the
-//                   cut has exact score < theta = tau * (1 + 2 EPS).
-//   5. exact        the survivors (tens, out of hundreds) are compacted into LDS and only they
-//                   get the exact fp64 normalisation (:111-119, two divisions and a square root),
-//                   `>= minScore` (:125), and the monotone 64-bit key
-//   6. emit         survivors with exact key >= key(theta): an exact upper set of the unit, plus
-//                   key(theta) so that the merge can prove the global top-k exact.
+// unit_fast_kernel   one workgroup = one unit; the unit's postings live in REGISTERS (U per thread: an fp32 copy of
+//               the score and the cluster's sequence number -- the fp64 posting is read again only for survivors).
+//               Measured instruction-issue / latency bound (profiles/r02_pmc_summary.txt), so everything is arranged
+//               to spend few instructions per posting and to keep eight workgroups on a CU (<= 64 VGPRs, 20 KB LDS):
+//   1. descriptors  coalesced read of the unit's (start, prefix) row; byte map flat posting index -> cluster;
+//                   per-cluster constants (fp64 weight, fp32 weight, and for the cosine forms the fp32 KEY of a
+//                   single-cluster candidate: (s w) / sqrt(s s) = w, so such a candidate needs no arithmetic)
+//   2. gather       one 16-B global load per posting, consecutive lanes = consecutive postings of a sub-list; all of a
+//                   thread's loads are issued (inline asm: hipcc otherwise waits after each) before the single wait;
+//                   age window and source-tweet filters (:90-91)
+//   5a'. cluster cut  (cosine forms, while the loads are in flight) wave 0 sorts the clusters by that key and scans
+//                   their posting counts: the cut is a property of the descriptors, known before any posting arrives
+//   3. duplicates   a tweet can sit in several scanned clusters (all its postings are in this unit by construction of
+//                   the partition hash).  Each posting ORs three hash bits into one 64-bit word of a blocked Bloom
+//                   filter with ONE LDS atomic; finding all already set flags the id.  Units with a flag (one in
+//                   five at the benchmark's shape) load their postings again and resolve the flagged ids through a
+//                   small match list, groups summed by one thread in cluster order, so fp64 sums follow the
+//                   reference's accumulation order (:83-100) whatever the timing.
+//   4. keys         APPROXIMATE fp32 score per live candidate (|approx/exact - 1| <= EPS), as an order-preserving u32
+//   5a. data cut    (other forms, or when 5a' kept too few) the kl-th largest of the 256 per-thread maxima, found by
+//                   an in-register bitonic sort per wave (DPP / permlane swaps) and a rank search in LDS
+//   5b. compact     survivors (key >= cut) into LDS as (cluster, posting position): one LDS atomic per wave
+//   6. exact        the survivors (tens, out of ~1250) are fetched again -- L2 hits -- and only they get the exact fp64
+//                   normalisation (:111-119, two divisions and a square root), `>= minScore` (:125), the monotone
+//                   64-bit key; emit those with key >= key(theta), theta = cut (1 + 2 EPS): an exact upper set of
+//                   the unit, plus key(theta) so that the merge can prove the global top-k exact.
 //
-// Units that do not fit (too many clusters / postings / flagged ids, scores outside the fp32
-// range, an unresolvable tie group) flag UNIT_OVERFLOW and are re-run by unit_general_kernel.
+// Units that do not fit (too many clusters / postings / flagged ids / survivors, scores outside the fp32 range) flag
+// UNIT_OVERFLOW and are re-run by unit_general_kernel.
+//
+// Build rule (csrc/Makefile, tools/check_unit_kernel_resources.py): no instantiation of unit_fast_kernel may use
+// scratch.  hipcc (ROCm 7.2) was seen to place a VGPR spill store in FRONT of the `s_or_b64 exec` that re-joins a
+// divergent branch, so lanes that sat the branch out reloaded garbage: results differed from run to run.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -273,13 +279,8 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   constexpr int BW = bloom_log2(WG * U);  // log2 of the Bloom filter's 64-bit words
   constexpr int BLOOM_ALLOC = 1 << BW;
   constexpr int HB = 18 + BW;  // hash bits: 3 x 6 bit positions, then the word index
-#ifdef SANN_EXP_FB7
-  constexpr int FBLOOM_WORDS = BW >= 11 ? 128 : 256;
-  constexpr int FB = BW >= 11 ? 7 : 8;
-#else
   constexpr int FBLOOM_WORDS = BW >= 11 ? 64 : 256;  // (beside the 16 KB Bloom filter: 64, so that eight workgroups fit a CU)
   constexpr int FB = BW >= 11 ? 6 : 8;
-#endif
   constexpr int MCAP = (WG * U <= 1024) ? 64 : 128;
   __shared__ unsigned long long s_bloom[BLOOM_ALLOC];
   __shared__ uint32_t s_begin[NS];
@@ -294,11 +295,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   // large enough.
   constexpr bool ALIAS = BLOOM_ALLOC >= SCAP + 128;
   constexpr int M_OFF = SCAP + 128;  // in 8-byte words: behind the survivor list and the histogram
-#ifdef SANN_EXP_NO_ALIAS_M
-  constexpr bool ALIAS_M = false;
-#else
   constexpr bool ALIAS_M = ALIAS && BLOOM_ALLOC >= M_OFF + 5 * MCAP;
-#endif
   __shared__ unsigned long long s_ent_own[ALIAS ? 1 : SCAP];
   __shared__ unsigned s_hist_own[ALIAS ? 1 : 256];
   __shared__ long long s_Mid_own[ALIAS_M ? 1 : MCAP];
@@ -675,9 +672,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
         bad = bad || (lv && !(seq[u] & 0x10000) && !(s32[u] > 1e-15f && s32[u] < 1e15f && wk != 0u));
         k32[u] = lv ? wk : 0u;
       }
-    }
-#ifndef SANN_EXP_COS_ONLY
-    else if (h.alg == 1) {
+    } else if (h.alg == 1) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const bool lv = seq[u] >= 0;
@@ -721,7 +716,6 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
         }
       }
     }
-#endif
     if (__ballot(bad) != 0ull && (tid & 63) == 0) atomicOr(&s_ctl[CTL_BAD], 1);
   }
   // ---- 5a. the cut: the kl-th largest LANE MAXIMUM ---------------------------------------------------------------
@@ -786,6 +780,8 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
         __syncthreads();
         tau = (uint32_t)s_ctl[CTL_SEL_D];
       }
+    } else {
+      STAMP(5);  // (cluster-level cut: the threshold was known before the keys)
     }
     STAMP(6);  // threshold found
     {
@@ -917,14 +913,13 @@ template <int WG, int U>
 static hipError_t launch_one(const IndexView &ix, const BatchView &b, const FastParams &fp, hipStream_t stream) {
   const int nq8 = (b.nq + 7) / 8 * 8;
   const int n_blocks = nq8 * ix.P;
-  static const int pad_lds = getenv("SANN_EXP_PAD_LDS") ? atoi(getenv("SANN_EXP_PAD_LDS")) : 0;  // experiment: caps occupancy
   if (fp.use_norms) {
     if (fp.max_n_scan <= 64)
       hipLaunchKernelGGL((unit_fast_kernel<WG, U, 64, 0, true>), dim3(n_blocks), dim3(WG), 0, stream, ix, b, fp.k_local, n_blocks);
     else
       hipLaunchKernelGGL((unit_fast_kernel<WG, U, NSCAN_MAX, 0, true>), dim3(n_blocks), dim3(WG), 0, stream, ix, b, fp.k_local, n_blocks);
   } else if (fp.max_n_scan <= 64)
-    hipLaunchKernelGGL((unit_fast_kernel<WG, U, 64>), dim3(n_blocks), dim3(WG), (size_t)pad_lds, stream, ix, b, fp.k_local, n_blocks);
+    hipLaunchKernelGGL((unit_fast_kernel<WG, U, 64>), dim3(n_blocks), dim3(WG), 0, stream, ix, b, fp.k_local, n_blocks);
   else
     hipLaunchKernelGGL((unit_fast_kernel<WG, U, NSCAN_MAX>), dim3(n_blocks), dim3(WG), 0, stream, ix, b, fp.k_local, n_blocks);
   return hipGetLastError();
