@@ -207,6 +207,17 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ inline uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
+// inclusive prefix sum over the wave, on the VALU (DPP row shifts, then the two row broadcasts)
+__device__ inline int wave_incl_scan_i32(int x) {
+  uint32_t v = (uint32_t)x;
+  v += dpp_u32<0x111, 0xf>(0u, v);  // row_shr:1
+  v += dpp_u32<0x112, 0xf>(0u, v);  // row_shr:2
+  v += dpp_u32<0x114, 0xf>(0u, v);  // row_shr:4
+  v += dpp_u32<0x118, 0xf>(0u, v);  // row_shr:8
+  v += dpp_u32<0x142, 0xa>(0u, v);  // row_bcast:15 -> rows 1, 3
+  v += dpp_u32<0x143, 0xc>(0u, v);  // row_bcast:31 -> rows 2, 3
+  return (int)v;
+}
 
 // Value of lane (l ^ J), without a trip through the LDS crossbar (a chain of 21 ds_bpermute round trips cost the
 // sort below ~6k cycles of latency): quad permutes, row shifts, and gfx950's row / half-wave swaps.
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   __shared__ double s_Msc_own[ALIAS_M ? 1 : MCAP], s_Mdot_own[ALIAS_M ? 1 : MCAP], s_Mnsq_own[ALIAS_M ? 1 : MCAP];
   __shared__ int s_Mseq_own[ALIAS_M ? 1 : MCAP], s_Mrole_own[ALIAS_M ? 1 : MCAP];
   __shared__ double s_Mnrm[NORMS ? MCAP : 1];  // offline forms: the full norm of the match-list entry's tweet
-  // survivor list: (cluster sequence number or 0x10000 | match-list entry) << 32 | position of the posting in the index
+  // survivor list: (cluster sequence number or 0x10000 | match-list entry) << 32 | flat index of the posting in the unit
   unsigned long long *const s_ent = ALIAS ? s_bloom : s_ent_own;
   unsigned *const s_hist = ALIAS ? reinterpret_cast<unsigned *>(s_bloom + SCAP) : s_hist_own;
   long long *const s_Mid = ALIAS_M ? reinterpret_cast<long long *>(s_bloom + M_OFF) : s_Mid_own;
@@ -667,9 +678,12 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const bool lv = seq[u] >= 0;
-        const uint32_t wk = s_wkey[lv ? (seq[u] & (NS - 1)) : 0];
-        // the shortcut is only trusted for ordinary positive magnitudes (s32^2 within the fp32 range, w / l2norm too)
-        bad = bad || (lv && !(seq[u] & 0x10000) && !(s32[u] > 1e-15f && s32[u] < 1e15f && wk != 0u));
+        const uint32_t wk = s_wkey[seq[u] & (NS - 1)];  // (dead slots and representatives read some entry: unused)
+        // the shortcut is only trusted for ordinary positive magnitudes (s32^2 within the fp32 range, w / l2norm too):
+        // 1e-15 < s32 < 1e15 as one unsigned compare of the bit pattern (negatives, NaN and inf fall outside)
+        constexpr uint32_t LO = 0x26901d7du, HI = 0x58635fa9u;  // 1e-15f, 1e15f
+        const bool ordinary = (__float_as_uint(s32[u]) - (LO + 1u)) < (HI - LO - 1u);
+        bad = bad || ((uint32_t)seq[u] < 0x10000u && !(ordinary && wk != 0u));
         k32[u] = lv ? wk : 0u;
       }
     } else if (h.alg == 1) {
@@ -793,27 +807,29 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
       ABLATE(4, x_ + tau);
     }
     // ---- 5b. compact the survivors: one LDS atomic per wave --------------------------------------------------------
+    // Survivors are few (tens per unit), so the bookkeeping is per THREAD, not per slot: a thread counts its own, a DPP
+    // prefix sum places it in the wave, one atomic places the wave in the unit, and an entry is just (cluster, flat
+    // posting index) -- the posting's address is worked out in phase 6, by the few threads that need it.  (Six rounds of
+    // ballot / mbcnt / descriptor reads here were 200 of the kernel's 790 VALU instructions per wave.)
     {
-      int total = 0;
+      const uint32_t tau_eff = tau ? tau : 1u;  // (a dead slot's key is 0)
+      int cnt = 0;
 #pragma unroll
-      for (int u = 0; u < U; u++) total += __popcll(__ballot(k32[u] != 0u && k32[u] >= tau));
+      for (int u = 0; u < U; u++) cnt += k32[u] >= tau_eff ? 1 : 0;
+      const int incl = wave_incl_scan_i32(cnt);
+      const int total = __builtin_amdgcn_readlane(incl, 63);
       int base = 0;
       if ((tid & 63) == 0 && total) base = atomicAdd(&s_ctl[CTL_NSURV], total);
-      base = __shfl(base, 0, 64);
-      const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (total != 0 && base + total <= SCAP) {  // uniform per wave; a list that would not fit is an overflow below
+        int o = base + incl - cnt;
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const bool sv = k32[u] != 0u && k32[u] >= tau;
-        const unsigned long long m = __ballot(sv);  // (recomputed rather than kept: six live masks cost 12 SGPRs)
-        if (sv) {
-          const int o = base + __popcll(m & below);
-          if (o < SCAP) {
-            const int c = seq[u];
-            const uint32_t pos = (c & 0x10000) ? 0u : s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c]);
-            s_ent[o] = ((unsigned long long)(uint32_t)c << 32) | pos;
+        for (int u = 0; u < U; u++) {
+          if (k32[u] >= tau_eff) {
+            s_ent[o] = ((unsigned long long)(uint32_t)seq[u] << 32) | (uint32_t)(u * WG + tid);
+            o++;
           }
         }
-        base += __popcll(m);
       }
     }
     __syncthreads();
@@ -881,11 +897,12 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
       dot = s_Mdot[c & 0xffff];
       nsq = s_Mnsq[c & 0xffff];
     } else {
-      const Posting ps = ix.postings[(uint32_t)e];
+      const uint32_t pos = s_begin[c] + ((uint32_t)e - s_pre[c]);
+      const Posting ps = ix.postings[pos];
       idv = ps.id;
       dot = 0.0 + ps.score * s_w[c];  // getOrElse(tweetId, 0.0) + score * sourceClusterScore  (:92-94)
       nsq = 0.0 + ps.score * ps.score;  // (:95-96)
-      if constexpr (NORMS) nsq = use_norms ? ix.norms[(uint32_t)e] : nsq;  // tweets_ann.sql:50-51
+      if constexpr (NORMS) nsq = use_norms ? ix.norms[pos] : nsq;  // tweets_ann.sql:50-51
     }
     const double v = normalise_f(h.alg, dot, nsq, h.l2norm, h.lognorm);
     const unsigned long long key = score_key(v);
