@@ -63,6 +63,12 @@ int hnsw_index_build_insert(int32_t device, int32_t metric, int64_t n, int32_t d
                             int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t n_threads, hnsw_index_t **out);
 
 /* The graph back as flat arrays (two calls: sizes, then contents) and the stored (fp16-rounded) vectors. */
+/* The same, with every item's level given by the caller instead of drawn (the reference draws it from a thread-local
+ * Random, HnswIndex.java:369-371): a deterministic rebuild, and the form the oracle's restatement of insert is compared
+ * with (tests/test_hnsw_build_gpu.py).  levels[i] in 0..60. */
+int hnsw_index_build_insert_levels(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors,
+                                   const int64_t *ids, int32_t max_m, int32_t ef_construction, const int32_t *levels,
+                                   int32_t n_threads, hnsw_index_t **out);
 int hnsw_index_graph_size(const hnsw_index_t *index, int64_t *n_entries, int64_t *n_neighbours, int64_t *entry_point,
                           int32_t *max_level);
 int hnsw_index_graph(const hnsw_index_t *index, int32_t *entry_level, int64_t *entry_item, int64_t *entry_offsets,

@@ -165,6 +165,26 @@ int sann_index_build_from_postings(const sann_index_options_t *opts, int32_t n_l
                                    const double *scaled_times, int64_t now_ms, int64_t half_life_ms, int32_t max_results,
                                    sann_index_t **out);
 /*
+ * The streaming side of the same store: the Summingbird job folds event batches into the per-cluster
+ * maps with TopKTweetsWithScoresMonoid.plus (summingbird/common/Monoids.scala:131-158), i.e.
+ * TopKScoresUtils.mergeTwoTopKMapWithDecayedValues (:378-450) and the tweet-age filter (:154).  For every list i
+ * (a CSR pair of sides a and b, entries = (tweet id, DecayedValue.value, DecayedValue.scaledTime); ids unique per side):
+ *   a side empty -> the other side, untouched (:388-394); otherwise every value is decayed to the latest scaledTime of
+ *   both sides (DecayedValueMonoid(0.0).plus with a zero at that time), kept if > threshold, the larger value wins for
+ *   an id on both sides, and when more than 1.2 x top_k entries remain only the top_k largest are kept (:441-448);
+ *   last, ids < oldest_tweet_id are dropped (:142,154).
+ * A map has no order: results are written by (value desc, tweet id asc), which is also the tie order of the cut (the
+ * reference's is its HashMap's iteration order).  One workgroup per list on the device; at most 4096 entries per list
+ * on both sides together (SANN_ELIMIT).  out_offsets[n_lists + 1] is always written; SANN_ELIMIT if out_capacity is
+ * too small (out_offsets then tells the size needed).  Production: top_k 1600, threshold 0.001, age 3 days / 1 hour
+ * (summingbird/common/Configs.scala:41,56,63-65).
+ */
+int sann_topk_merge(int32_t device, int32_t n_lists, const int64_t *a_offsets, const int64_t *a_ids, const double *a_values,
+                    const double *a_scaled_times, const int64_t *b_offsets, const int64_t *b_ids, const double *b_values,
+                    const double *b_scaled_times, int32_t top_k, double threshold, int64_t oldest_tweet_id,
+                    int64_t out_capacity, int64_t *out_offsets, int64_t *out_ids, double *out_values,
+                    double *out_scaled_times);
+/*
  * Generate the synthetic SimClusters corpus of SURVEY.md section 8(d) on the device and build
  * the index from it without a host round trip (per-cluster filter -> sort by score descending
  * -> cap -> partition: the device form of TopKTweetsForClusterReadableStore.scala:211-229).

@@ -1,5 +1,5 @@
 /*
- * hnsw_oracle.c -- CPU restatement of the reference's HNSW query walk.  TEST INFRASTRUCTURE ONLY.
+ * hnsw_oracle.c -- CPU restatement of the reference's HNSW query walk and of its index construction.  TEST INFRASTRUCTURE ONLY.
  *
  * Follows (paths relative to /root/reference/ann/src/main/java/com/twitter/ann/hnsw/):
  *   HnswIndex.java:538-553   searchKnn: descend to layer 0, beam search with max(ef, k), dequeueAll, reverse, cut
@@ -165,4 +165,205 @@ int32_t oracle_hnsw_search(int32_t metric, int64_t n, int32_t d, const float *x,
   for (int l = 0; l <= max_level; l++) free(lookup[l]);
   free(lookup);
   return m;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Index construction: HnswIndex.insert restated (single writer: the locks of the Java code order nothing then).
+ *   HnswIndex.java:150-199   insert: duplicate check, level, entry point / max level, wire, entry-point update
+ *   HnswIndex.java:137-148   wireConnectionForAllLayers
+ *   HnswIndex.java:571-623   searchLayerForCandidates (isUpdate = false), with distFnIndex (item to item)
+ *   HnswIndex.java:384-440   mutuallyConnectNewElement
+ *   HnswIndex.java:479-526   selectNearestNeighboursByHeuristic
+ *   DistancedItemQueue.java:111-118,176-189   toListWithItem / reverse: both walk the PriorityQueue's ARRAY order
+ * The level of every item is an input (the reference draws (int)(-ln U / ln maxM) from a thread-local Random, :369-371).
+ * Item-to-item distances use the arithmetic of hdistance() with the first item's stored row as the query.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int64_t n;
+  int metric, d, max_m, max_m0, efc, n_levels, cap;
+  const float *x;
+  int32_t **cnt;   /* [level][item]: list length, -1 = the graph has no HnswNode(level, item) */
+  int64_t **nb;    /* [level][item * cap + i] */
+  int64_t entry;   /* -1 = Optional.empty() */
+  int max_level;   /* HnswMeta starts at (-1, empty), :97 */
+} hbuild;
+
+static float item_distance(const hbuild *g, int64_t a, int64_t b) { /* distFnIndex.distance(a, b) */
+  dist_ctx c = {g->metric, g->d, g->x, g->x + (size_t)a * g->d};
+  return hdistance(&c, b);
+}
+static int list_of(const hbuild *g, int level, int64_t item, const int64_t **out) { /* getConnectionListForRead / getOrDefault */
+  if (level < 0 || level >= g->n_levels || g->cnt[level][item] < 0) { *out = NULL; return 0; }
+  *out = g->nb[level] + (size_t)item * g->cap;
+  return g->cnt[level][item];
+}
+static void put_list(hbuild *g, int level, int64_t item, const int64_t *list, int n) { /* graph.put(HnswNode.from(level, item), ...) */
+  memcpy(g->nb[level] + (size_t)item * g->cap, list, sizeof(int64_t) * (size_t)n);
+  g->cnt[level][item] = n;
+}
+
+/* candidates: a MAX queue whose origin is `base`; returns the number of neighbours written to out (<= max_conn) */
+static int select_by_heuristic(const hbuild *g, const jpq *cand, int64_t base, int max_conn, int64_t *out) {
+  int m = 0;
+  if (cand->n <= max_conn) { /* :488-491 toListWithItem (array order), remove the first occurrence of the base */
+    int removed = 0;
+    for (int i = 0; i < cand->n; i++) {
+      if (!removed && cand->a[i].item == base) { removed = 1; continue; }
+      out[m++] = cand->a[i].item;
+    }
+    return m;
+  }
+  jpq minq; /* :495 candidates.reverse(): re-offer in array order under the reversed comparator */
+  jpq_init(&minq, 1);
+  for (int i = 0; i < cand->n; i++) jpq_offer(&minq, cand->a[i]);
+  while (minq.n > 0) {
+    if (m >= max_conn) break;
+    qitem c = jpq_poll(&minq);
+    if (c.item == base) continue; /* :505-507 */
+    int include = 1;
+    for (int i = 0; i < m; i++) {
+      float dist = item_distance(g, out[i], c.item); /* distFnIndex.distance(e, candidate) */
+      if (dist < c.d) { include = 0; break; }
+    }
+    if (include) out[m++] = c.item;
+  }
+  free(minq.a);
+  return m;
+}
+
+static void search_layer(const hbuild *g, int64_t item, int64_t entry, int ef, int level, uint8_t *visited, jpq *wq) {
+  jpq cq;
+  jpq_init(&cq, 1);
+  jpq_init(wq, 0);
+  qitem first = {item_distance(g, item, entry), entry};
+  jpq_offer(&cq, first);
+  jpq_offer(wq, first);
+  memset(visited, 0, (size_t)g->n);
+  visited[entry] = 1;
+  float lower = wq->a[0].d;
+  while (cq.n > 0) {
+    qitem cand = cq.a[0];
+    if (cand.d > lower) break;
+    jpq_poll(&cq);
+    const int64_t *list;
+    int ln = list_of(g, level, cand.item, &list);
+    for (int j = 0; j < ln; j++) {
+      int64_t nn = list[j];
+      if (visited[nn]) continue;
+      visited[nn] = 1;
+      float dist = item_distance(g, item, nn);
+      if (wq->n < ef || dist < wq->a[0].d) {
+        qitem it = {dist, nn};
+        jpq_offer(&cq, it);
+        jpq_offer(wq, it);
+        if (wq->n > ef) jpq_poll(wq);
+        lower = wq->a[0].d;
+      }
+    }
+  }
+  free(cq.a);
+}
+
+static int64_t mutually_connect(hbuild *g, int64_t item, const jpq *cand, int level) {
+  int64_t *neigh = malloc(sizeof(int64_t) * (size_t)(g->cap + 1));
+  int64_t *upd = malloc(sizeof(int64_t) * (size_t)(g->cap + 1));
+  int nn = select_by_heuristic(g, cand, item, g->max_m, neigh); /* :392 maxM on every level */
+  put_list(g, level, item, neigh, nn);                            /* :393 */
+  const int M = level == 0 ? g->max_m0 : g->max_m;
+  for (int i = 0; i < nn; i++) {
+    int64_t other = neigh[i];
+    if (other == item) continue;
+    const int64_t *conn;
+    int cn = list_of(g, level, other, &conn);
+    if (cn < M) { /* :414-417 append */
+      memcpy(upd, conn, sizeof(int64_t) * (size_t)cn);
+      upd[cn] = item;
+      put_list(g, level, other, upd, cn + 1);
+    } else { /* :419-427 max queue around `other` holding its connections, plus the new item */
+      jpq q;
+      jpq_init(&q, 0);
+      for (int j = 0; j < cn; j++) { qitem it = {item_distance(g, other, conn[j]), conn[j]}; jpq_offer(&q, it); }
+      qitem it = {item_distance(g, other, item), item};
+      jpq_offer(&q, it);
+      int un = select_by_heuristic(g, &q, other, M, upd);
+      put_list(g, level, other, upd, un);
+      free(q.a);
+    }
+  }
+  int64_t first = neigh[0]; /* :439 neighbours.get(0) */
+  free(neigh);
+  free(upd);
+  return first;
+}
+
+/* Inserts items 0 .. n-1 in order.  Output: the graph's entries sorted by (level, item), as oracle_hnsw_search reads
+ * them; returns the number of entries (or -1 if the output arrays are too small). */
+int64_t oracle_hnsw_build(int32_t metric, int64_t n, int32_t d, const float *x, const int32_t *levels, int32_t max_m,
+                          int32_t ef_construction, int64_t cap_entries, int64_t cap_neighbours, int32_t *entry_level,
+                          int64_t *entry_item, int64_t *entry_offsets, int64_t *entry_neighbours, int64_t *entry_point,
+                          int32_t *max_level) {
+  hbuild g;
+  g.n = n; g.metric = metric; g.d = d; g.max_m = max_m; g.max_m0 = 2 * max_m; g.efc = ef_construction; g.x = x;
+  g.cap = 2 * max_m + 1;
+  g.entry = -1; g.max_level = -1;
+  int top = 0;
+  for (int64_t i = 0; i < n; i++) if (levels[i] > top) top = levels[i];
+  g.n_levels = top + 1;
+  g.cnt = malloc(sizeof(int32_t *) * (size_t)g.n_levels);
+  g.nb = malloc(sizeof(int64_t *) * (size_t)g.n_levels);
+  for (int l = 0; l < g.n_levels; l++) {
+    g.cnt[l] = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; i++) g.cnt[l][i] = -1;
+    g.nb[l] = malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1) * (size_t)g.cap);
+  }
+  uint8_t *visited = malloc((size_t)(n > 0 ? n : 1));
+  for (int64_t item = 0; item < n; item++) {
+    const int cur_level = levels[item];      /* :165 */
+    const int64_t entry = g.entry;           /* :166 */
+    const int max_copy = g.max_level;        /* :170 */
+    if (entry >= 0) {                        /* :184-186 wireConnectionForAllLayers(entry, item, curLevel, maxLevelCopy) */
+      int64_t cur = entry;
+      if (cur_level < max_copy) {            /* bestEntryPointUntilLayer(cur, item, maxLayer, itemLevel), :447-475 */
+        float cur_dist = item_distance(&g, item, cur);
+        for (int level = max_copy; level > cur_level; level--) {
+          int changed = 1;
+          while (changed) {
+            changed = 0;
+            const int64_t *list;
+            int ln = list_of(&g, level, cur, &list);
+            for (int j = 0; j < ln; j++) {
+              float t = item_distance(&g, item, list[j]);
+              if (t < cur_dist) { cur_dist = t; cur = list[j]; changed = 1; }
+            }
+          }
+        }
+      }
+      for (int level = cur_level < max_copy ? cur_level : max_copy; level >= 0; level--) {
+        jpq wq;
+        search_layer(&g, item, cur, g.efc, level, visited, &wq);
+        cur = mutually_connect(&g, item, &wq, level);
+        free(wq.a);
+      }
+    }
+    if (cur_level > max_copy) { g.max_level = cur_level; g.entry = item; } /* :188-193 */
+  }
+  int64_t ne = 0, nnb = 0;
+  int fits = 1;
+  for (int l = 0; l < g.n_levels && fits; l++)
+    for (int64_t i = 0; i < n; i++) {
+      if (g.cnt[l][i] < 0) continue;
+      if (ne >= cap_entries || nnb + g.cnt[l][i] > cap_neighbours) { fits = 0; break; }
+      entry_level[ne] = l;
+      entry_item[ne] = i;
+      entry_offsets[ne] = nnb;
+      memcpy(entry_neighbours + nnb, g.nb[l] + (size_t)i * g.cap, sizeof(int64_t) * (size_t)g.cnt[l][i]);
+      nnb += g.cnt[l][i];
+      ne++;
+    }
+  if (fits) entry_offsets[ne] = nnb;
+  *entry_point = g.entry;
+  *max_level = g.max_level;
+  for (int l = 0; l < g.n_levels; l++) { free(g.cnt[l]); free(g.nb[l]); }
+  free(g.cnt); free(g.nb); free(visited);
+  return fits ? ne : -1;
 }

@@ -263,6 +263,26 @@ def hnsw_search(metric: int, stored: np.ndarray, graph, query: np.ndarray, k: in
     return out_i[:m].copy(), out_d[:m].copy(), evals.value
 
 
+def hnsw_build(metric: int, stored: np.ndarray, levels, max_m: int, ef_construction: int):
+    """HnswIndex.insert for items 0 .. n-1 in order, each at its given level (oracle/hnsw_oracle.c, oracle_hnsw_build),
+    over fp16-rounded stored vectors.  Returns the graph in the form hnsw_search takes, entries sorted by (level, item)."""
+    L = lib()
+    L.oracle_hnsw_build.restype = C.c_int64
+    x = np.ascontiguousarray(stored, np.float32)
+    lv_in = np.ascontiguousarray(levels, np.int32)
+    n = x.shape[0]
+    cap_e = n * (int(lv_in.max(initial=0)) + 1) + 1
+    cap_n = cap_e * (2 * max_m + 1)
+    e_lv = np.zeros(cap_e, np.int32); e_it = np.zeros(cap_e, np.int64)
+    e_off = np.zeros(cap_e + 1, np.int64); e_nb = np.zeros(cap_n, np.int64)
+    entry = C.c_int64(); ml = C.c_int32()
+    ne = L.oracle_hnsw_build(C.c_int32(metric), C.c_int64(n), C.c_int32(x.shape[1]), _p(x), _p(lv_in), C.c_int32(max_m),
+                             C.c_int32(ef_construction), C.c_int64(cap_e), C.c_int64(cap_n), _p(e_lv), _p(e_it), _p(e_off),
+                             _p(e_nb), C.byref(entry), C.byref(ml))
+    assert ne >= 0
+    return e_lv[:ne].copy(), e_it[:ne].copy(), e_off[:ne + 1].copy(), e_nb[:e_off[ne]].copy(), entry.value, ml.value
+
+
 # ---------------------------------------------------------------------------------------------
 # The offline all-users job: src/scala/com/twitter/simclusters_v2/scio/bq_generation/sql/tweets_ann.sql:1-64, restated
 # step by step in plain Python (small inputs only).  It is the reference's only INDEPENDENT statement of the
@@ -332,6 +352,47 @@ def store_list(tweet_ids, values, scaled_times, now_scaled, max_results):
     out_s = np.zeros(len(t) + 1, np.float64)
     m = L.oracle_store_list(len(t), _p(t), _p(v), _p(st), float(now_scaled), int(max_results), _p(out_i), _p(out_s))
     return out_i[:m].copy(), out_s[:m].copy()
+
+
+def topk_merge(a, b, top_k: int, threshold: float, oldest_tweet_id: int):
+    """TopKTweetsWithScoresMonoid.plus for ONE cluster, restated literally with dicts (small inputs only):
+    src/scala/com/twitter/simclusters_v2/summingbird/common/Monoids.scala:131-158 (plus, age filter :142,154) and
+    :378-450 (TopKScoresUtils.mergeTwoTopKMapWithDecayedValues).  a, b: {tweetId: (value, scaledTime)} or None.
+    ThriftDecayedValueMonoid.plus(v, DecayedValue(0.0, latest)) is algebird's DecayedValueMonoid(0.0).plus (un-vendored;
+    restated in oracle_decay_to_timestamp, zero = DecayedValue(0.0, -inf)).  The cut's order among equal values is the
+    HashMap's in the reference; here (value desc, tweet id asc), as everywhere."""
+    L = lib()
+    L.oracle_decay_to_timestamp.restype = C.c_double
+    L.oracle_decay_to_timestamp.argtypes = [C.c_double, C.c_double, C.c_double]
+
+    def age(m):
+        return None if m is None else {k: v for k, v in m.items() if k >= oldest_tweet_id}  # :154
+
+    if a is None or len(a) == 0:        # :388-390
+        return age(b)
+    if b is None or len(b) == 0:        # :392-394
+        return age(a)
+    latest = max(t for _v, t in list(a.values()) + list(b.values()))  # :396-399
+
+    def decayed(value, t):              # :409-410
+        nv = L.oracle_decay_to_timestamp(float(value), float(t), float(latest))
+        return (nv, latest) if nv != 0.0 else (0.0, float("-inf"))
+
+    merged = {}
+    for k, (v, t) in a.items():         # :405-417
+        d = decayed(v, t)
+        if d[0] > threshold:
+            merged[k] = d
+    for k, (v, t) in b.items():         # :419-438
+        d = decayed(v, t)
+        if d[0] > threshold:
+            if k not in merged:
+                merged[k] = d
+            elif d[0] > merged[k][0]:
+                merged[k] = d
+    if len(merged) > top_k * 1.2:       # :441-448
+        merged = dict(sorted(merged.items(), key=lambda kv: (-kv[1][0], kv[0]))[:top_k])
+    return age(merged)
 
 
 def strict_log(x: float) -> float:

@@ -139,3 +139,22 @@ def test_store_list_hand_cases(oracle):
     assert abs(got_s[2] - 1.0) <= 1e-10 and abs(got_s[3] - 0.5) <= 1e-10
     assert oracle.store_list(ids, vals, st, sc(now), 2)[0].tolist() == [7, 10]          # take(2)
     assert oracle.store_list(ids, vals, None, 0.0, 10)[0].tolist() == [6, 7, 10, 5]    # no decay: 4, 2, 2, 1
+
+
+def test_topk_merge_hand_cases(oracle):
+    """TopKTweetsWithScoresMonoid.plus by hand: one half-life = ln 2 in scaled time."""
+    ln2 = math.log(2.0)
+    a = {1: (1.0, 0.0), 2: (0.3, 0.0), 3: (0.0015, 0.0)}
+    b = {1: (0.4, ln2), 4: (0.25, ln2), 2: (0.2, ln2)}
+    got = oracle.topk_merge(a, b, 10, 0.001, 0)
+    # a decays by exactly 1/2: tweet 1 keeps a's 0.5 (> b's 0.4), tweet 2 takes b's 0.2 (> 0.15), tweet 3 falls to
+    # 0.00075 < threshold, tweet 4 is b's alone; every survivor sits at the latest time
+    assert set(got) == {1, 2, 4}
+    assert got[1] == (pytest.approx(0.5, rel=1e-15), ln2) and got[2] == (0.2, ln2) and got[4] == (0.25, ln2)
+    # an empty side returns the other untouched (no decay, no threshold), but the age filter still applies
+    assert oracle.topk_merge({}, {5: (1e-9, 3.0), 9: (2.0, 1.0)}, 1, 0.5, 6) == {9: (2.0, 1.0)}
+    assert oracle.topk_merge(None, None, 1, 0.5, 0) is None
+    # the cut fires only above 1.2 x topK entries: 12 entries, topK 10 -> kept; 13 -> the 10 largest
+    many = {i: (float(i), 0.0) for i in range(1, 13)}
+    assert len(oracle.topk_merge(many, {100: (0.5, 0.0)}, 10, 0.0, 0)) == 10
+    assert len(oracle.topk_merge({i: (float(i), 0.0) for i in range(1, 12)}, {100: (0.5, 0.0)}, 10, 0.0, 0)) == 12

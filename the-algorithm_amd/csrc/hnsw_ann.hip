@@ -821,8 +821,27 @@ int hnsw_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const
   return HNSW_OK;
 }
 
+static int build_insert_impl(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                             int32_t max_m, int32_t ef_construction, uint64_t seed, const int32_t *given_levels,
+                             int32_t n_threads, hnsw_index_t **out);
+
 int hnsw_index_build_insert(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
                             int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t n_threads, hnsw_index_t **out) {
+  return build_insert_impl(device, metric, n, d, vectors, ids, max_m, ef_construction, seed, nullptr, n_threads, out);
+}
+
+int hnsw_index_build_insert_levels(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors,
+                                   const int64_t *ids, int32_t max_m, int32_t ef_construction, const int32_t *levels,
+                                   int32_t n_threads, hnsw_index_t **out) {
+  if (!levels && n > 0) return fail(HNSW_EINVAL, "levels is NULL");
+  for (int64_t i = 0; i < n; ++i)
+    if (levels[i] < 0 || levels[i] > 60) return fail(HNSW_EINVAL, "a level is outside 0..60");
+  return build_insert_impl(device, metric, n, d, vectors, ids, max_m, ef_construction, 0, levels, n_threads, out);
+}
+
+static int build_insert_impl(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                             int32_t max_m, int32_t ef_construction, uint64_t seed, const int32_t *given_levels,
+                             int32_t n_threads, hnsw_index_t **out) {
   if (!out) return fail(HNSW_EINVAL, "out is NULL");
   if (ef_construction < 1) return fail(HNSW_EINVAL, "ef_construction must be positive");
   if (n_threads < 1 || n_threads > 256) return fail(HNSW_EINVAL, "n_threads must be in 1..256");
@@ -833,6 +852,10 @@ int hnsw_index_build_insert(int32_t device, int32_t metric, int64_t n, int32_t d
   const double level_mult = 1.0 / std::log(1.0 * max_m);  // HnswIndex.java:118
   std::vector<int32_t> levels((size_t)n);
   for (int64_t i = 0; i < n; ++i) {
+    if (given_levels) {
+      levels[(size_t)i] = given_levels[i];
+      continue;
+    }
     const uint64_t h = sann::mix64(seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull));
     const double u = ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740992.0);  // (0, 1]
     levels[(size_t)i] = std::min(60, (int)(-std::log(u) * level_mult));       // getRandomLevel, :369-371

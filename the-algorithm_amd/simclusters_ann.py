@@ -145,6 +145,8 @@ _PROTOS = {
     "sann_index_build": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "sann_index_build_with_norms": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "sann_index_build_from_postings": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "sann_topk_merge": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int32, C.c_double, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sann_index_build_synthetic": (C.c_int, [C.POINTER(sann_index_options_t), C.POINTER(sann_synth_params_t), C.POINTER(C.c_void_p)]),
     "sann_synth_tweet_embeddings": (C.c_int, [C.c_int32, C.POINTER(sann_synth_params_t), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sann_synth_exact_cosine_topk": (C.c_int, [C.c_int32, C.POINTER(sann_synth_params_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -234,6 +236,25 @@ def _check(rc: int) -> None:
 
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def topk_merge(a, b, *, top_k: int = 1600, threshold: float = 0.001, oldest_tweet_id: int = -(1 << 63), device: int = 0):
+    """TopKTweetsWithScoresMonoid.plus for a batch of clusters (sann_topk_merge; Monoids.scala:131-158,378-450).
+    a, b: (offsets int64[n+1], tweet_ids, values, scaled_times) CSR sides.  Returns the merged side in the same form,
+    every list ordered by (value desc, tweet id asc)."""
+    lib = load_library()
+    ao, ai, av, at = (np.ascontiguousarray(x, dtype=d) for x, d in zip(a, (np.int64, np.int64, np.float64, np.float64)))
+    bo, bi, bv, bt = (np.ascontiguousarray(x, dtype=d) for x, d in zip(b, (np.int64, np.int64, np.float64, np.float64)))
+    if len(ao) != len(bo) or len(ao) < 1:
+        raise ValueError("both sides need offsets for the same number of lists")
+    n = len(ao) - 1
+    cap = int(len(ai) + len(bi))
+    oo = np.zeros(n + 1, np.int64)
+    oi = np.zeros(max(cap, 1), np.int64); ov = np.zeros(max(cap, 1)); ot = np.zeros(max(cap, 1))
+    _check(lib.sann_topk_merge(device, n, _ptr(ao), _ptr(ai), _ptr(av), _ptr(at), _ptr(bo), _ptr(bi), _ptr(bv), _ptr(bt),
+                               int(top_k), float(threshold), int(oldest_tweet_id), cap, _ptr(oo), _ptr(oi), _ptr(ov), _ptr(ot)))
+    m = int(oo[n])
+    return oo, oi[:m].copy(), ov[:m].copy(), ot[:m].copy()
 
 
 class ClusterTweetIndex:
