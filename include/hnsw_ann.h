@@ -73,6 +73,10 @@ int hnsw_index_graph_size(const hnsw_index_t *index, int64_t *n_entries, int64_t
                           int32_t *max_level);
 int hnsw_index_graph(const hnsw_index_t *index, int32_t *entry_level, int64_t *entry_item, int64_t *entry_offsets,
                      int64_t *entry_neighbours);
+/* n vectors of dimension d, the metric and maxM the index was created with; the keys searches return (positions
+ * when the index was given no ids) */
+int hnsw_index_info(const hnsw_index_t *index, int64_t *n, int32_t *d, int32_t *metric, int32_t *max_m);
+int hnsw_index_get_ids(const hnsw_index_t *index, int64_t *out);
 int hnsw_index_get_vectors(const hnsw_index_t *index, int64_t i0, int64_t n, float *out);
 int hnsw_index_destroy(hnsw_index_t *index);
 

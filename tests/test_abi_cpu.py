@@ -28,6 +28,11 @@ def test_library_exports_every_declared_symbol(pkg):
     assert declared_hn == set(pkg.hnsw_ann.PROTOS)
     for name in sorted(declared_hn):
         assert hasattr(lib, name), f"{name} declared in include/hnsw_ann.h but not exported"
+    codec = open(os.path.join(ROOT, "include", "ann_codec.h")).read()
+    declared_codec = set(re.findall(r"\b((?:sann_wire|hnsw_codec|ann_wire|ann_codec|hnsw_index)_[a-z_0-9]+)\s*\(", codec))
+    assert declared_codec == set(pkg.ann_codec.PROTOS)
+    for name in sorted(declared_codec):
+        assert hasattr(lib, name), f"{name} declared in include/ann_codec.h but not exported"
     dann = open(os.path.join(ROOT, "include", "dense_ann.h")).read()
     declared_dann = set(re.findall(r"\b(dann_[a-z_0-9]+)\s*\(", dann))
     assert declared_dann == set(pkg.dense_ann.PROTOS)

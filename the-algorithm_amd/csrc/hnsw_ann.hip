@@ -954,6 +954,27 @@ int hnsw_index_get_vectors(const hnsw_index_t *ix, int64_t i0, int64_t n, float 
   return HNSW_OK;
 }
 
+int hnsw_index_info(const hnsw_index_t *ix, int64_t *n, int32_t *d, int32_t *metric, int32_t *max_m) {
+  if (!ix) return fail(HNSW_EINVAL, "NULL index");
+  if (n) *n = ix->n;
+  if (d) *d = ix->d;
+  if (metric) *metric = ix->metric;
+  if (max_m) *max_m = ix->m;
+  return HNSW_OK;
+}
+
+int hnsw_index_get_ids(const hnsw_index_t *ix, int64_t *out) {
+  if (!ix || (!out && ix->n > 0)) return fail(HNSW_EINVAL, "NULL argument");
+  if (ix->n == 0) return HNSW_OK;
+  if (!ix->has_ids) {
+    for (int64_t i = 0; i < ix->n; ++i) out[i] = i;
+    return HNSW_OK;
+  }
+  HTRY(hipSetDevice(ix->device));
+  HTRY(hipMemcpy(out, ix->ids.p, (size_t)ix->n * 8, hipMemcpyDeviceToHost));
+  return HNSW_OK;
+}
+
 int hnsw_index_destroy(hnsw_index_t *ix) {
   delete ix;
   return HNSW_OK;

@@ -27,6 +27,8 @@ PROTOS = {
                                                  C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "hnsw_index_graph_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "hnsw_index_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hnsw_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "hnsw_index_get_ids": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hnsw_index_get_vectors": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "hnsw_index_destroy": (C.c_int, [C.c_void_p]),
     "hnsw_search": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -129,6 +129,15 @@ class SimClustersANNConfig:
             0,
         )
 
+    @classmethod
+    def from_c(cls, c: sann_config_t) -> "SimClustersANNConfig":
+        try:
+            alg = ScoringAlgorithm(c.ann_algorithm)
+        except ValueError:
+            alg = c.ann_algorithm  # an id this build does not know: carried as the wire has it
+        return cls(c.max_num_results, c.min_score, c.candidate_embedding_type, c.max_top_tweets_per_cluster, c.max_scan_clusters,
+                   c.max_tweet_candidate_age_hours, c.min_tweet_candidate_age_hours, alg)
+
 
 class SannError(RuntimeError):
     def __init__(self, code: int, msg: str):
