@@ -25,6 +25,7 @@
 #include "sann_kernels.h"
 #include "sann_math.h"
 #include "sann_select.h"
+#include "sann_wave.h"
 
 namespace sann {
 
@@ -438,6 +439,95 @@ __device__ void lds_radix_cut(const uint64_t *hi, const uint64_t *lo, int n, int
   thr_lo = pre_lo;
 }
 
+// Number of entries of the descending 64-entry run L that come BEFORE the key (xh, xl): strictly greater ones, and -- when
+// ties_before -- equal ones (only padding entries can be equal; the flag makes the order total).
+__device__ inline int run_count_before(const ulonglong2 *L, uint64_t xh, uint64_t xl, bool ties_before) {
+  int pos = 0;
+#pragma unroll
+  for (int step = 32; step >= 1; step >>= 1) {
+    const ulonglong2 v = L[pos + step - 1];
+    const bool before = v.x > xh || (v.x == xh && (v.y > xl || (v.y == xl && ties_before)));
+    pos += before ? step : 0;
+  }
+  const ulonglong2 v = L[63];  // 64 entries = 63 reachable by the steps above, plus the last one
+  const bool before = v.x > xh || (v.x == xh && (v.y > xl || (v.y == xl && ties_before)));
+  return pos + ((pos == 63 && before) ? 1 : 0);
+}
+
+// The same for all the other runs of a sorted-runs array at once: the searches advance in lock step, so that every
+// step has one LDS read per run in flight instead of a chain of 7 x (runs - 1) dependent reads.
+template <int RMAX>
+__device__ inline int rank_among_runs(const ulonglong2 *runs, int R, int r, int lane, uint64_t xh, uint64_t xl) {
+  int pos[RMAX];
+#pragma unroll
+  for (int r2 = 0; r2 < RMAX; r2++) pos[r2] = 0;
+#pragma unroll
+  for (int step = 32; step >= 1; step >>= 1) {
+    ulonglong2 v[RMAX];
+#pragma unroll
+    for (int r2 = 0; r2 < RMAX; r2++) v[r2] = r2 < R ? runs[r2 * 64 + pos[r2] + step - 1] : make_ulonglong2(0ull, 0ull);
+#pragma unroll
+    for (int r2 = 0; r2 < RMAX; r2++) {
+      const bool before = v[r2].x > xh || (v[r2].x == xh && (v[r2].y > xl || (v[r2].y == xl && r2 < r)));
+      pos[r2] += before ? step : 0;
+    }
+  }
+  int rank = lane;
+#pragma unroll
+  for (int r2 = 0; r2 < RMAX; r2++) {
+    const ulonglong2 v = r2 < R ? runs[r2 * 64 + 63] : make_ulonglong2(0ull, 0ull);
+    const bool before = v.x > xh || (v.x == xh && (v.y > xl || (v.y == xl && r2 < r)));
+    const int p2 = pos[r2] + ((pos[r2] == 63 && before) ? 1 : 0);
+    rank += (r2 < R && r2 != r) ? p2 : 0;
+  }
+  return rank;
+}
+
+// A threshold with need <= #{key >= thr} <= budget from a SAMPLE instead of radix passes: every thread contributes one
+// staged entry, the WG = 256 samples are sorted (four in-register wave sorts + a rank merge: two barriers), and the
+// sample at the position the window's middle is expected at is tried -- one counting sweep per try, the next try moved
+// by the miss.  Returns false (after at most 6 tries, or when two neighbouring samples bracket the window) and leaves
+// the decision to lds_radix_cut; needs n >= WG.  s_tmp: WG entries, s_ctl: 4 ints.
+__device__ bool sample_cut(const uint64_t *hi, const uint64_t *lo, int n, int need, int budget, ulonglong2 *s_tmp, int *s_ctl,
+                           uint64_t &thr_hi, uint64_t &thr_lo) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int idx = (int)(((long long)tid * n) / WG);
+  uint64_t sh = hi[idx], sl = lo[idx];
+  wave_sort_desc_k128(sh, sl);
+  s_tmp[tid] = make_ulonglong2(sh, sl);
+  __syncthreads();
+  const int rank = rank_among_runs<WG / 64>(s_tmp, WG / 64, wv, lane, sh, sl);
+  __syncthreads();
+  s_tmp[rank] = make_ulonglong2(sh, sl);  // (ranks are a permutation)
+  __syncthreads();
+  const int target = (need + budget) / 2;
+  int j = (int)(((long long)target * WG) / n) - 1;
+  j = j < 0 ? 0 : (j > WG - 1 ? WG - 1 : j);
+  int j_small = -1, j_big = WG;  // samples known to give too few / too many
+  for (int attempt = 0; attempt < 6; attempt++) {
+    const ulonglong2 t = s_tmp[j];
+    int c = 0;
+    for (int i = tid; i < n; i += WG) c += key_ge(hi[i], lo[i], t.x, t.y) ? 1 : 0;
+    const int tot = __builtin_amdgcn_readlane(wave_incl_scan_i32(c), 63);
+    if (lane == 0) s_ctl[wv] = tot;
+    __syncthreads();
+    const int C = s_ctl[0] + s_ctl[1] + s_ctl[2] + s_ctl[3];
+    __syncthreads();
+    if (C >= need && C <= budget) {
+      thr_hi = t.x;
+      thr_lo = t.y;
+      return true;
+    }
+    if (C < need) j_small = j; else j_big = j;
+    if (j_big - j_small <= 1) return false;
+    int step = (int)(((long long)(target - C) * WG) / n);
+    if (step == 0) step = C < need ? 1 : -1;
+    j += step;
+    j = j <= j_small ? j_small + 1 : (j >= j_big ? j_big - 1 : j);
+  }
+  return false;
+}
+
 // SURV = capacity of the survivor list: 512 when every k of the batch is <= 448, else 1024.  The staging
 // area holds 1728 entries for SURV = 512: 39.8 KB of LDS in all, FOUR workgroups per CU, so a 1024-query batch
 // merges in one round of workgroups (at 2048 entries it was 44 KB, three per CU, two rounds: twice the time).
@@ -454,7 +544,6 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   __shared__ int s_off[WG + 1];
   __shared__ int s_fb[WG];
   __shared__ int s_ctl[4];
-  __shared__ int s_cnt;
 
   const int tid = threadIdx.x;
   const int q = query_list ? query_list[blockIdx.x] : blockIdx.x;
@@ -491,6 +580,19 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   int64_t *out_ids = (int64_t *)((char *)b.out_ids + out_shift) + (int64_t)ql * b.stride;
   double *out_scores = (double *)((char *)b.out_scores + out_shift) + (int64_t)ql * b.stride;
 
+  // what the exactness proof at the end reads per unit (P <= WG: one unit per thread), fetched now so that the two
+  // dependent trips to memory are long over when the sort is
+  int pf_unique = 0;
+  uint32_t pf_T = 0, pf_flags = 0;
+  uint64_t pf_thi = 0, pf_tlo = 0;
+  if (tid < P) {
+    const int64_t unit = unit0 + tid;
+    pf_unique = b.unit_unique[unit];
+    pf_T = b.q_stat ? (uint32_t)b.unit_T[unit] : 0u;
+    pf_flags = b.unit_flags[unit];
+    pf_thi = b.unit_thr[2 * unit];
+    pf_tlo = b.unit_thr[2 * unit + 1];
+  }
   MSTAMP(1);  // offsets
   int best_n = 0;  // entries currently in s_e2
   int u_begin = 0;
@@ -544,40 +646,82 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
     __syncthreads();
     MSTAMP(2);  // staged (last round)
     uint64_t thi = 0, tlo = 0;
-    if (n > budget && k > 0) lds_radix_cut(s_hi, s_lo, n, k, budget, s_hist, s_ctl, s_mm, thi, tlo);
-    MSTAMP(3);  // cut found (last round)
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += WG) {
-      const uint64_t a = s_hi[i], c = s_lo[i];
-      if (k > 0 && key_ge(a, c, thi, tlo)) {
-        const int o = atomicAdd(&s_cnt, 1);
-        if (o < SURV) s_e2[o] = make_ulonglong2(a, c);
-      }
+    if (n > budget && k > 0) {
+      // (s_e2 is free here: the previous round's survivors were copied into the staging area above)
+      if (!sample_cut(s_hi, s_lo, n, k, budget, s_e2, s_ctl, thi, tlo))
+        lds_radix_cut(s_hi, s_lo, n, k, budget, s_hist, s_ctl, s_mm, thi, tlo);
     }
-    __syncthreads();
-    best_n = s_cnt < SURV ? s_cnt : SURV;
+    MSTAMP(3);  // cut found (last round)
+    // survivors into s_e2: per-thread counts, a DPP prefix sum per wave, wave bases through LDS -- no atomics
+    {
+      int c = 0;
+      if (k > 0)
+        for (int i = tid; i < n; i += WG) c += key_ge(s_hi[i], s_lo[i], thi, tlo) ? 1 : 0;
+      const int incl = wave_incl_scan_i32(c);
+      if ((tid & 63) == 63) s_ctl[tid >> 6] = incl;
+      __syncthreads();
+      int o = incl - c;
+      for (int w = 0; w < (tid >> 6); w++) o += s_ctl[w];
+      const int total = s_ctl[0] + s_ctl[1] + s_ctl[2] + s_ctl[3];
+      if (k > 0)
+        for (int i = tid; i < n; i += WG) {
+          const uint64_t a = s_hi[i], c2 = s_lo[i];
+          if (key_ge(a, c2, thi, tlo)) {
+            if (o < SURV) s_e2[o] = make_ulonglong2(a, c2);
+            o++;
+          }
+        }
+      best_n = total < SURV ? total : SURV;
+    }
     u_begin = u_end;
     __syncthreads();
   }
 
   MSTAMP(4);  // compacted
-  // sort the survivors, keep the first k
+  // sort the survivors, keep the first k: every wave sorts runs of 64 in registers (DPP / permlane network, no barriers),
+  // the runs meet in LDS, and every entry finds its final position by binary searches in the other runs and goes
+  // straight to the output -- two barriers instead of the 45 barrier-separated stages of an LDS bitonic sort
   uint64_t xk_hi = 0, xk_lo = 0;
   {
-    const int np = next_pow2(best_n);
+    int np = next_pow2(best_n);
+    np = np < 64 ? 64 : np;
     for (int i = best_n + tid; i < np; i += WG) s_e2[i] = make_ulonglong2(0ull, 0ull);
+    if (tid == 0) { s_mm[0] = 0ull; s_mm[1] = 0ull; }
     __syncthreads();
-    bitonic_sort_desc_packed(s_e2, np);
-    MSTAMP(5);  // sorted
-    const int cnt = best_n < k ? best_n : k;
-    for (int i = tid; i < cnt; i += WG) {
-      const ulonglong2 v = s_e2[i];
-      out_ids[i] = key_id(v.y);
-      out_scores[i] = key_score(v.x);
+    const int R = np >> 6, lane = tid & 63, wv = tid >> 6;
+    constexpr int PER = SURV / WG < 1 ? 1 : SURV / WG;
+    uint64_t mh[PER], ml[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const int r = wv + j * (WG / 64);
+      mh[j] = 0ull;
+      ml[j] = 0ull;
+      if (r < R) {  // (uniform per wave)
+        const ulonglong2 v = s_e2[r * 64 + lane];
+        mh[j] = v.x;
+        ml[j] = v.y;
+        wave_sort_desc_k128(mh[j], ml[j]);
+        s_e2[r * 64 + lane] = make_ulonglong2(mh[j], ml[j]);
+      }
     }
-    if (cnt == k && cnt > 0) { xk_hi = s_e2[cnt - 1].x; xk_lo = s_e2[cnt - 1].y; }
+    __syncthreads();
+    MSTAMP(5);  // runs sorted
+    const int cnt = best_n < k ? best_n : k;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const int r = wv + j * (WG / 64);
+      if (r < R) {
+        const int rank = rank_among_runs<(SURV + 63) / 64>(s_e2, R, r, lane, mh[j], ml[j]);
+        if (rank < cnt) {
+          out_ids[rank] = key_id(ml[j]);
+          out_scores[rank] = key_score(mh[j]);
+          if (rank == cnt - 1 && cnt == k) { s_mm[0] = mh[j]; s_mm[1] = ml[j]; }  // the k-th key
+        }
+      }
+    }
     if (tid == 0) ((int32_t *)((char *)b.out_counts + out_shift))[ql] = cnt;
+    __syncthreads();
+    if (cnt == k && cnt > 0) { xk_hi = s_mm[0]; xk_lo = s_mm[1]; }
   }
   __syncthreads();
   // candidateScoresMap.size (:102) and the exactness proof: every candidate a unit withheld has
@@ -585,18 +729,11 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   // k results there is no k-th key, so any withholding unit makes the result unproven.
   int msz = 0, inexact = 0;
   uint32_t t_max = 0, t_sum = 0;
-  for (int u = tid; u < P; u += WG) {
-    const int64_t unit = unit0 + u;
-    msz += b.unit_unique[unit];
-    if (b.q_stat) {
-      const uint32_t T = (uint32_t)b.unit_T[unit];
-      t_max = T > t_max ? T : t_max;
-      t_sum += T;
-    }
-    if (k > 0 && (b.unit_flags[unit] & UNIT_TRUNCATED)) {
-      const uint64_t thi = b.unit_thr[2 * unit], tlo = b.unit_thr[2 * unit + 1];
-      if (key_gt(thi, tlo, xk_hi, xk_lo)) inexact = 1;
-    }
+  if (tid < P) {
+    msz = pf_unique;
+    t_max = pf_T;
+    t_sum = pf_T;
+    if (k > 0 && (pf_flags & UNIT_TRUNCATED) && key_gt(pf_thi, pf_tlo, xk_hi, xk_lo)) inexact = 1;
   }
   if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; }
   __syncthreads();
