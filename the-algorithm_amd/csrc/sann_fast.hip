@@ -318,12 +318,16 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   __syncthreads();
   STAMP(1);  // descriptors + map done
 
-  // entries a unit must offer before it may withhold the rest (its share of k, six sigma, and a few), and the size
-  // up to which it simply offers everything
+  // entries a unit must offer before it may withhold the rest (its share of k, five sigma, and a few), and the size
+  // up to which it simply offers everything.  Tweets are hashed to partitions, so the number of a query's final top-k
+  // that sit in one unit is Binomial(k, 1/P): at k = 400, P = 32 (mean 12.5) the bound is 34, exceeded with probability
+  // ~1e-7 per unit -- one query re-run through the general path per ~300 batches of 32768 units.  (Six sigma + 8 = 41
+  // made every unit offer seven more candidates than that: 1760 instead of 1540 per query, and half of the queries
+  // needed a second staging round in the merge kernel.)
   int kl;
   {
     const float share = (float)h.k / (float)ix.P;
-    kl = (int)(share + 6.0f * sqrtf(share) + 8.0f);
+    kl = (int)(share + 5.0f * sqrtf(share) + 4.0f);
     if (kl < k_local_floor) kl = k_local_floor;
     if (kl > h.k) kl = h.k;
     if (kl > SCAP - 32) kl = SCAP - 32;
