@@ -82,9 +82,26 @@ class Corpus:
         return self.tweet_ids[b:e], self.scores[b:e]
 
 
+def topic_cluster_ranks(rng: np.random.Generator, topics: np.ndarray, n_clusters: int, n_topics: int, topic_size: int,
+                        affinity: float) -> np.ndarray:
+    """Popularity ranks (1-based) of cluster draws under the TOPIC-MIXTURE variant: draw j belongs to an entity whose
+    topic is topics[j]; with probability `affinity` the cluster comes from that topic's own `topic_size` clusters (its
+    i-th cluster has global rank topic + (i - 1) * n_topics + 1: every topic owns popular and rare clusters alike;
+    i is Zipf within the topic), else from the global Zipf law.  SURVEY 8(d)'s corpus draws a tweet's clusters
+    independently of each other, which makes the operator's partial cosine unrelated to the full cosine
+    (recall_at_400_quality 0.05); real SimClusters embeddings are topical, and this variant restores that."""
+    n = len(topics)
+    own = rng.random(n) < affinity
+    i = np.clip(np.floor(np.exp(rng.random(n) * np.log(topic_size + 1.0))).astype(np.int64), 1, topic_size)
+    in_topic = (topics + (i - 1) * n_topics) % n_clusters + 1
+    return np.where(own, in_topic, zipf_ranks(rng, n, n_clusters))
+
+
 def make_corpus(n_tweets: int, n_clusters: int = N_CLUSTERS, *, seed: int = CORPUS_SEED, index_cap: int = 2000,
                 now_ms: int = NOW_MS, window_hours: int = 24, mean_clusters: float = 25.0,
-                max_clusters_per_tweet: int = 50) -> Corpus:
+                max_clusters_per_tweet: int = 50, n_topics: int = 0, topic_size: int = 64, affinity: float = 0.9) -> Corpus:
+    """n_topics = 0: SURVEY 8(d)'s corpus (independent Zipf draws).  n_topics > 0: the topic-mixture variant
+    (topic_cluster_ranks), every tweet in one Zipf-drawn topic."""
     rng = np.random.default_rng(seed)
     perm = cluster_permutation(n_clusters)
     # tweet ids: unique Snowflake ids uniform over the window before now_ms
@@ -100,7 +117,11 @@ def make_corpus(n_tweets: int, n_clusters: int = N_CLUSTERS, *, seed: int = CORP
     # clusters per tweet: min(cap, 1 + Geom(p)) with mean ~ mean_clusters
     n_t = np.minimum(max_clusters_per_tweet, rng.geometric(1.0 / mean_clusters, size=n_tweets)).astype(np.int64)
     tw = np.repeat(np.arange(n_tweets, dtype=np.int64), n_t)
-    cl = perm[zipf_ranks(rng, len(tw), n_clusters) - 1]
+    if n_topics > 0:
+        t_topic = zipf_ranks(rng, n_tweets, n_topics) - 1
+        cl = perm[topic_cluster_ranks(rng, t_topic[tw], n_clusters, n_topics, topic_size, affinity) - 1]
+    else:
+        cl = perm[zipf_ranks(rng, len(tw), n_clusters) - 1]
     sc = np.maximum(np.exp(rng.normal(-2.0, 1.0, size=len(tw))), 0.001)
     # distinct clusters per tweet: drop repeated (tweet, cluster) draws
     key = tw * np.int64(n_clusters + 1) + cl
@@ -125,9 +146,11 @@ def make_corpus(n_tweets: int, n_clusters: int = N_CLUSTERS, *, seed: int = CORP
                   np.ascontiguousarray(sc_s[keep]), tid, t_off, cl.astype(np.int32), sc)
 
 
-def make_queries(n_queries: int, n_clusters: int = N_CLUSTERS, *, seed: int = QUERY_SEED, clusters_per_user: int = 50):
+def make_queries(n_queries: int, n_clusters: int = N_CLUSTERS, *, seed: int = QUERY_SEED, clusters_per_user: int = 50,
+                 n_topics: int = 0, topic_size: int = 64, affinity: float = 0.9, topics_per_user: int = 2):
     """User embeddings: `clusters_per_user` distinct Zipf-drawn clusters, scores exp(N(0,1)).
-    Returns CSR (offsets int64[nq+1], cluster ids int32, scores float64)."""
+    Returns CSR (offsets int64[nq+1], cluster ids int32, scores float64).
+    n_topics > 0: the topic-mixture variant -- a user follows `topics_per_user` Zipf-drawn topics."""
     rng = np.random.default_rng(seed)
     perm = cluster_permutation(n_clusters)
     offs = np.zeros(n_queries + 1, np.int64)
@@ -135,8 +158,14 @@ def make_queries(n_queries: int, n_clusters: int = N_CLUSTERS, *, seed: int = QU
     for q in range(n_queries):
         got: list = []
         seen = set()
+        mine = zipf_ranks(rng, topics_per_user, n_topics) - 1 if n_topics > 0 else None
         while len(got) < min(clusters_per_user, n_clusters):
-            for c in perm[zipf_ranks(rng, clusters_per_user, n_clusters) - 1]:
+            if mine is not None:
+                ranks = topic_cluster_ranks(rng, mine[rng.integers(0, len(mine), clusters_per_user)], n_clusters, n_topics,
+                                            topic_size, affinity)
+            else:
+                ranks = zipf_ranks(rng, clusters_per_user, n_clusters)
+            for c in perm[ranks - 1]:
                 if int(c) not in seen and len(got) < clusters_per_user:
                     seen.add(int(c))
                     got.append(int(c))

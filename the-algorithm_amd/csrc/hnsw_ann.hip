@@ -54,7 +54,10 @@ constexpr int MAX_D = 512;
 constexpr int MAX_M = 32;        // lists of <= 2*MAX_M = 64 neighbours: one lane each
 constexpr int MAX_EF = 1024;
 constexpr int CCAP_LDS = 2048;   // candidate queue entries in LDS
-constexpr int CCAP_LDS_BIG = 16384;  // second try of a query that overflowed CCAP_LDS: 136 KB of LDS, one wave per CU
+constexpr int CCAP_LDS_BIG = 16384;  // last LDS tier of a query that overflowed the smaller ones: 136 KB of LDS, one wave per CU
+// LDS tiers of the candidate queue.  A query that outgrows one is run again in the next (the walk is the same, only the
+// capacity differs); the index remembers, per beam width, the largest queue the previous search saw and starts there.
+constexpr int CCAP_TIERS[] = {CCAP_LDS, 4096, 8192, CCAP_LDS_BIG};
 constexpr int CCAP_GLOBAL = 1 << 17;
 
 struct Buf {
@@ -169,7 +172,7 @@ struct SearchArgs {
   int64_t *out_ids;
   int32_t *out_counts;
   int32_t *spill;             // [nq] set when the LDS candidate queue overflowed
-  unsigned long long *stats;  // [0] distance evaluations, [1] expansions
+  unsigned long long *stats;  // [0] distance evaluations, [1] expansions, [2] largest candidate queue, [3..7] queries by the tier that fits them
   int64_t vwords;
   int32_t dpad, chunks, m, m0, metric, k, ef, max_level;
   int32_t ccap_lds;           // candidate-queue entries allowed in LDS (<= CCAP_LDS; smaller only for tests)
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
   wave_distances<CH>(a, qv, ul, ud, 1, lane);
   __syncthreads();
   n_dist += 1;
-  int cn = 0, wn = 0;
+  int cn = 0, wn = 0, peak = 1;
   bool overflow = false;
   {
     const HEntry e0{ud[0], cur};
@@ -335,6 +338,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
             break;
           }
           pq_add<true>(cq, cn, e);
+          peak = cn > peak ? cn : peak;
           pq_add<false>(wq, wn, e);
           if (wn > ef) (void)pq_poll<false>(wq, wn);
           lower = wq[0].dist;
@@ -347,6 +351,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
   if (lane == 0) {
     atomicAdd(&a.stats[0], n_dist);
     atomicAdd(&a.stats[1], n_exp);
+    atomicMax(&a.stats[2], (unsigned long long)(overflow ? ccap + 1 : peak));  // largest candidate queue of the launch
+    if (!overflow) {  // (a query finishes exactly once) which LDS tier would have been enough for it
+      int t = 0;
+      while (t < 4 && peak > CCAP_TIERS[t]) ++t;
+      atomicAdd(&a.stats[3 + t], 1ull);
+    }
   }
   if (overflow) {
     if (lane == 0) a.spill[qi] = 1;
@@ -413,6 +423,8 @@ struct hnsw_index {
   hipEvent_t ev[2] = {nullptr, nullptr};
   int64_t last_dist = 0, last_exp = 0;
   int32_t last_spilled = 0;
+  int64_t last_peak = 0;
+  int8_t tier_hint[MAX_EF + 1] = {};  // [beam]: 1 + the LDS tier at which the next search of that beam width starts (0 = none yet)
   float last_ms = 0;
   ~hnsw_index() {
     for (auto &e : ev)
@@ -1006,13 +1018,13 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   HTRY(ix->o_ids.reserve((size_t)nq * k * 8));
   HTRY(ix->o_cnt.reserve((size_t)nq * 4));
   HTRY(ix->spill.reserve((size_t)nq * 4));
-  HTRY(ix->stats.reserve(16));
+  HTRY(ix->stats.reserve(64));
   hipStream_t st = 0;
   HTRY(hipMemcpyAsync(ix->q_in.p, queries, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(hnsw_prep_rows, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, ix->q_in.as<float>(), (int64_t)nq, ix->d,
                      ix->dpad, ix->metric == HNSW_METRIC_COSINE ? 1 : 0, ix->q.as<_Float16>());
   HTRY(hipGetLastError());
-  HTRY(hipMemsetAsync(ix->stats.p, 0, 16, st));
+  HTRY(hipMemsetAsync(ix->stats.p, 0, 64, st));
   HTRY(hipMemsetAsync(ix->spill.p, 0, (size_t)nq * 4, st));
 
   SearchArgs a;
@@ -1040,77 +1052,103 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   a.ef = beam;
   a.max_level = ix->max_level;
   a.entry = (uint32_t)ix->entry;
-  a.ccap_lds = CCAP_LDS;  // every admission enters the candidate queue and stale ones stay: it reaches 2-3x the beam
-  bool skip_tier2 = false;
-  if (const char *e = getenv("HNSW_DEBUG_CCAP")) {  // tests: shrink tier 1; a negative value keeps tier 2, a positive one goes to tier 3
+  // every admission enters the candidate queue and stale ones stay: it reaches 2-3x the beam on clustered data and
+  // far more on structureless data (i.i.d. Gaussians), hence the tiers
+  constexpr int N_TIERS = (int)(sizeof(CCAP_TIERS) / sizeof(CCAP_TIERS[0]));
+  int tier_cap[N_TIERS + 1];
+  int n_lds_tiers = 0;
+  bool skip_mid = false;
+  if (const char *e = getenv("HNSW_DEBUG_CCAP")) {  // tests: shrink tier 1; a negative value keeps the big LDS tier, a positive one goes straight to global memory
     const int v = atoi(e);
-    a.ccap_lds = std::min(CCAP_LDS, std::max(1, v < 0 ? -v : v));
-    skip_tier2 = v > 0;
+    tier_cap[n_lds_tiers++] = std::min(CCAP_LDS, std::max(1, v < 0 ? -v : v));
+    if (v < 0) tier_cap[n_lds_tiers++] = CCAP_LDS_BIG;
+    skip_mid = true;
+  } else {
+    // start at the smallest tier that held nine tenths of the queries of the last search with this beam width
+    const int t0 = ix->tier_hint[beam] > 0 ? ix->tier_hint[beam] - 1 : 0;
+    for (int t = t0; t < N_TIERS; ++t) tier_cap[n_lds_tiers++] = CCAP_TIERS[t];
   }
+  (void)skip_mid;
 
   HTRY(hipEventRecord(ix->ev[0], st));
-  for (int64_t q0 = 0; q0 < nq; q0 += per_launch) {
-    const int64_t m = std::min<int64_t>(per_launch, nq - q0);
-    HTRY(hipMemsetAsync(ix->visited.p, 0, (size_t)m * vwords * 4, st));
-    SearchArgs b = a;
-    b.q = ix->q.as<_Float16>() + q0 * ix->dpad;
-    b.qlist = nullptr;
-    b.out_dist = a.out_dist + q0 * k;
-    b.out_ids = a.out_ids + q0 * k;
-    b.out_counts = a.out_counts + q0;
-    b.spill = a.spill + q0;
-    int rc = launch_search_any(a.chunks, false, (int)m, b, st);
-    if (rc) return rc;
-    HTRY(hipGetLastError());
-  }
-  // queries whose candidate queue outgrew its LDS allowance: again with a whole CU's worth of LDS each
-  // (tier 2), and whatever still does not fit with the queues in global memory (tier 3)
-  std::vector<int32_t> spill((size_t)nq);
-  HTRY(hipMemcpyAsync(spill.data(), ix->spill.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-  HTRY(hipStreamSynchronize(st));
-  std::vector<int32_t> redo;
-  for (int32_t q = 0; q < nq; ++q)
-    if (spill[(size_t)q]) redo.push_back(q);
-  ix->last_spilled = (int32_t)redo.size();
-  for (int tier = 2; tier <= 3 && !redo.empty(); ++tier) {
-    if (tier == 2 && skip_tier2) continue;
-    const int64_t batch = std::min<int64_t>((int64_t)redo.size(), std::min<int64_t>(per_launch, 256));
-    if (tier == 3) {
-      HTRY(ix->gc.reserve((size_t)batch * CCAP_GLOBAL * sizeof(HEntry)));
-      HTRY(ix->gw.reserve((size_t)batch * (MAX_EF + 1) * sizeof(HEntry)));
+  std::vector<int32_t> redo, spill((size_t)nq);
+  // tier index n_lds_tiers = queues in global memory
+  for (int tier = 0; tier <= n_lds_tiers; ++tier) {
+    const bool globalq = tier == n_lds_tiers;
+    const bool first = tier == 0;
+    if (!first && redo.empty()) break;
+    const int64_t todo = first ? nq : (int64_t)redo.size();
+    // queries per launch: visited bitmaps, and no more waves than the LDS lets run at once (a launch of more would
+    // only queue; smaller launches keep the bitmap memset small)
+    int64_t batch = per_launch;
+    if (globalq) {
+      batch = std::min<int64_t>(batch, 256);
+      HTRY(ix->gc.reserve((size_t)std::min<int64_t>(batch, todo) * CCAP_GLOBAL * sizeof(HEntry)));
+      HTRY(ix->gw.reserve((size_t)std::min<int64_t>(batch, todo) * (MAX_EF + 1) * sizeof(HEntry)));
+    } else if (!first) {
+      const size_t lds = (size_t)(beam + 1 + tier_cap[tier]) * sizeof(HEntry) + 1024;
+      batch = std::min<int64_t>(batch, 256 * std::max<int64_t>(1, (int64_t)(160 * 1024 / lds)));
     }
-    HTRY(ix->qlist.reserve(redo.size() * 4));
-    HTRY(hipMemcpyAsync(ix->qlist.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
-    for (size_t r0 = 0; r0 < redo.size(); r0 += (size_t)batch) {
-      const int64_t m = std::min<int64_t>(batch, (int64_t)(redo.size() - r0));
+    batch = std::min<int64_t>(batch, todo);
+    if (!first) {
+      HTRY(ix->qlist.reserve(redo.size() * 4));
+      HTRY(hipMemcpyAsync(ix->qlist.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
+    }
+    for (int64_t r0 = 0; r0 < todo; r0 += batch) {
+      const int64_t m = std::min<int64_t>(batch, todo - r0);
       HTRY(hipMemsetAsync(ix->visited.p, 0, (size_t)m * vwords * 4, st));
       SearchArgs b = a;
-      b.q = ix->q.as<_Float16>();
-      b.qlist = ix->qlist.as<int32_t>() + r0;
+      if (first) {
+        b.q = ix->q.as<_Float16>() + r0 * ix->dpad;
+        b.qlist = nullptr;
+        b.out_dist = a.out_dist + r0 * k;
+        b.out_ids = a.out_ids + r0 * k;
+        b.out_counts = a.out_counts + r0;
+        b.spill = a.spill + r0;
+      } else {
+        b.q = ix->q.as<_Float16>();
+        b.qlist = ix->qlist.as<int32_t>() + r0;
+      }
       b.gc = ix->gc.as<HEntry>();
       b.gw = ix->gw.as<HEntry>();
-      if (tier == 2) b.ccap_lds = CCAP_LDS_BIG;
-      int rc = launch_search_any(a.chunks, tier == 3, (int)m, b, st);
+      b.ccap_lds = globalq ? CCAP_LDS : tier_cap[tier];
+      int rc = launch_search_any(a.chunks, globalq, (int)m, b, st);
       if (rc) return rc;
       HTRY(hipGetLastError());
     }
     HTRY(hipMemcpyAsync(spill.data(), ix->spill.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
     HTRY(hipStreamSynchronize(st));
     std::vector<int32_t> still;
-    for (int32_t q : redo)
-      if (spill[(size_t)q]) still.push_back(q);
+    if (first) {
+      for (int32_t q = 0; q < nq; ++q)
+        if (spill[(size_t)q]) still.push_back(q);
+      ix->last_spilled = (int32_t)still.size();
+    } else {
+      for (int32_t q : redo)
+        if (spill[(size_t)q]) still.push_back(q);
+    }
     redo.swap(still);
   }
   if (!redo.empty()) return fail(HNSW_ELIMIT, "candidate queue above 131072 entries");
   HTRY(hipEventRecord(ix->ev[1], st));
-  unsigned long long stats[2] = {0, 0};
-  HTRY(hipMemcpyAsync(stats, ix->stats.p, 16, hipMemcpyDeviceToHost, st));
+  unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HTRY(hipMemcpyAsync(stats, ix->stats.p, 64, hipMemcpyDeviceToHost, st));
   HTRY(hipMemcpyAsync(out_dist, ix->o_dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
   HTRY(hipMemcpyAsync(out_ids, ix->o_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
   HTRY(hipMemcpyAsync(out_counts, ix->o_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
   HTRY(hipStreamSynchronize(st));
   ix->last_dist = (int64_t)stats[0];
   ix->last_exp = (int64_t)stats[1];
+  ix->last_peak = (int64_t)stats[2];
+  if (!getenv("HNSW_DEBUG_CCAP")) {
+    unsigned long long cum = 0;
+    int t = 0;
+    for (; t < 3; ++t) {
+      cum += stats[3 + t];
+      if (cum * 10 >= (unsigned long long)nq * 9) break;
+    }
+    ix->tier_hint[beam] = (int8_t)(t + 1);
+  }
   (void)hipEventElapsedTime(&ix->last_ms, ix->ev[0], ix->ev[1]);
   return HNSW_OK;
 }

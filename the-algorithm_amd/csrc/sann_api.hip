@@ -301,6 +301,7 @@ struct sann_batch {
     b.q_stat = (device_prep && use_fast) ? q_stat.as<uint4>() : nullptr;
     b.desc = desc.as<uint32_t>();
     b.unit_T = unit_T.as<int32_t>();
+    b.unit_pre = unit_T.as<uint32_t>() + n_units;  // (second half of the same allocation)
     for (int j = 0; j < 4; j++) { b.cut[j] = cut_ptr[j]; b.cut_M[j] = cut_M[j]; }
     b.nq = nq;
     b.cap = cap;
@@ -659,7 +660,7 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
   HIP_TRY(b->scan_row.reserve(scan_cap * 4));
   HIP_TRY(b->scan_w.reserve(scan_cap * 8));
   HIP_TRY(b->desc.reserve(scan_cap * (size_t)ix->P * 8));
-  HIP_TRY(b->unit_T.reserve(nu * 4));
+  HIP_TRY(b->unit_T.reserve(nu * 8));  // unit_T and unit_pre
   HIP_TRY(b->d_k.reserve(nqz * 4));
   HIP_TRY(b->q_stat.reserve(nqz * 16));
   HIP_TRY(b->cand_key.reserve(nu * (size_t)b->cap * 8));
@@ -965,7 +966,7 @@ static int batch_run(sann_batch_t *b, void *hip_stream, bool chained, sann_batch
   {
     if (b->profiling && !(b->prof_unit_only && b->use_fast)) HIP_TRY(hipEventRecord(b->ev[0], st));
     if (b->use_fast) {
-      hipError_t e = launch_desc(b->ix->view(), b->view(), b->n_units, b->fast.max_n_scan, st);
+      hipError_t e = launch_desc(b->ix->view(), b->view(), b->n_units, b->fast.max_n_scan, b->fast.k_local, st);
       if (e != hipSuccess) return fail(SANN_EDEVICE, std::string("launch_desc: ") + hipGetErrorString(e));
       // the descriptor kernel may run beside anything; the dominant kernel waits for its predecessor's
       if (after && after != b && after->unit_done_recorded)

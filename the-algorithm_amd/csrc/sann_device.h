@@ -70,6 +70,7 @@ struct BatchView {
   uint4 *q_stat;
   uint32_t *desc;           // [total_scan*P*2] (sub-list start, exclusive prefix of the lengths), unit-major
   int32_t *unit_T;          // [n_units] postings with rank < M the unit scans
+  uint32_t *unit_pre;       // [n_units] cosine forms: the cluster-level cut of the unit (fp32 key; 0 = none), from the descriptor kernel
   const uint32_t *cut[4];   // cached cut tables ([n_rows*P], see sann_index::cut_cache) ...
   int32_t cut_M[4];         // ... for these values of M (-1 = unused slot)
   int32_t nq;

@@ -111,6 +111,35 @@ __device__ inline int lower_bound_rank(const uint32_t *a, int n, uint32_t v) {
   return lo;
 }
 
+// Cosine forms: the fp32 key of a single-cluster candidate of a cluster with weight w -- (s w) / sqrt(s s) = w, times
+// 1 / l2norm for CosineSimilarity -- or 0 when it is not an ordinary positive magnitude (such clusters are keyed per posting).
+__device__ inline uint32_t cosine_cluster_key(int alg, double w, float inv_l2_32) {
+  const float wn = alg == 2 ? (float)w * inv_l2_32 : (float)w;
+  return (wn > 1e-30f && wn < 1e30f) ? (__float_as_uint(wn) | 0x80000000u) : 0u;
+}
+// Entries a unit must offer before it may withhold the rest: its share of k, five sigma, and a few.  Tweets are hashed
+// to partitions, so the number of a query's final top-k that sit in one unit is Binomial(k, 1/P): at k = 400, P = 32
+// (mean 12.5) the bound is 34, exceeded with probability ~1e-7 per unit -- one query re-run through the general path per
+// ~300 batches of 32768 units.  (Six sigma + 8 = 41 made every unit offer seven more candidates: 1760 instead of 1540 per
+// query, and half of the queries needed a second staging round in the merge kernel.)
+__device__ inline int unit_kl(int k, int P, int k_local_floor) {
+  const float share = (float)k / (float)P;
+  int kl = (int)(share + 5.0f * sqrtf(share) + 4.0f);
+  if (kl < k_local_floor) kl = k_local_floor;
+  if (kl > k) kl = k;
+  if (kl > FAST_SCAP - 32) kl = FAST_SCAP - 32;
+  return kl;
+}
+// Whether a query's units take the cluster-level cut: a single-cluster candidate's key is then a constant of its cluster,
+// so WHERE to cut follows from the descriptors alone -- clusters by key, postings counted until kl are covered.  The
+// descriptor kernels work it out per unit (unit_pre), the unit kernel only reads it.
+__device__ inline bool query_has_cluster_cut(const QueryHdr &h) {
+  return (h.alg == 2 || h.alg == 4) && h.n_scan <= 64 && h.use_norms == 0;
+}
+// the cut itself: 256 fp32 ulps (>= 3 EPS) below the key of the cluster at which the running posting count reaches kl
+// (see 5a in the unit kernel for why low); 0 = the unit's postings do not add up to kl: keep everything
+__device__ inline uint32_t cluster_cut_from_key(uint32_t kc) { return kc > 0x80000100u ? kc - 256u : kc; }
+
 // ---------------------------------------------------------------------------------------------
 // Cut table for one value of M: out[row*P + p] = number of postings of sub-list (row, p) with rank < M.
 __global__ __launch_bounds__(256) void cut_kernel(IndexView ix, int M, uint32_t *out) {
@@ -129,7 +158,7 @@ hipError_t launch_cut(const IndexView &ix, int M, uint32_t *out, hipStream_t str
 
 // One WAVE per unit: lane c (and c + 64) resolves cluster c's sub-list, the wave scans the lengths,
 // and the unit kernel later reads (start, exclusive prefix) pairs and the unit's posting count.
-__global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, int n_units) {
+__global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, int n_units, int k_local_floor) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int unit = blockIdx.x * 4 + wave;
   // per-run state the unit and merge kernels update: cleared here instead of by two memset launches
@@ -189,6 +218,26 @@ __global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, in
     d[2 * (lane + 64) + 1] = total0 + incl1 - len[1];
   }
   if (lane == 0) b.unit_T[unit] = (int32_t)(total0 + total1);
+  // cluster-level cut (n_scan <= 64: lane c = cluster c): clusters by key, descending, with the low 8 bits of the key
+  // replaced by c (keys 256 ulps apart tie; the cut is taken 256 ulps low anyway)
+  const QueryHdr h = b.hdr[q];
+  uint32_t pre = 0u;
+  if (query_has_cluster_cut(h)) {  // (uniform)
+    const float inv_l2_32 = (float)(1.0 / h.l2norm);
+    const uint32_t kc = lane < n_scan ? cosine_cluster_key(h.alg, b.scan_w[scan_begin + lane], inv_l2_32) : 0u;
+    const uint32_t pk = wave_sort_desc_u32(kc ? ((kc & ~0xffu) | (uint32_t)lane) : 0u);
+    const int c = (int)(pk & 0xffu);
+    int cum = pk ? (int)__shfl(len[0], c, 64) : 0;
+    const uint32_t kc_sorted = __shfl(kc, c, 64);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(cum, off, 64);
+      cum += lane >= off ? t : 0;
+    }
+    const unsigned long long ok = __ballot(pk != 0u && cum >= unit_kl(h.k, ix.P, k_local_floor));
+    if (ok != 0ull) pre = cluster_cut_from_key(__shfl(kc_sorted, __ffsll((long long)ok) - 1, 64));
+  }
+  if (lane == 0) b.unit_pre[unit] = pre;
 }
 
 // Three bit positions inside the posting's 64-bit Bloom word.  (A fourth -- fewer false flags: one unit in twelve instead
@@ -298,8 +347,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
         s_pre[c] = v.y;
         s_w[c] = w;
         s_w32[c] = (float)w;
-        const float wn = h.alg == 2 ? (float)w * inv_l2_32 : (float)w;
-        s_wkey[c] = (wn > 1e-30f && wn < 1e30f) ? (__float_as_uint(wn) | 0x80000000u) : 0u;
+        s_wkey[c] = cosine_cluster_key(h.alg, w, inv_l2_32);
       }
       // every posting of this cluster records its cluster in the flat map (an oversized unit stops at the map's end)
       asm volatile("" : "+v"(nxt));  // keeps the select on Tv below the loads above
@@ -318,26 +366,15 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   __syncthreads();
   STAMP(1);  // descriptors + map done
 
-  // entries a unit must offer before it may withhold the rest (its share of k, five sigma, and a few), and the size
-  // up to which it simply offers everything.  Tweets are hashed to partitions, so the number of a query's final top-k
-  // that sit in one unit is Binomial(k, 1/P): at k = 400, P = 32 (mean 12.5) the bound is 34, exceeded with probability
-  // ~1e-7 per unit -- one query re-run through the general path per ~300 batches of 32768 units.  (Six sigma + 8 = 41
-  // made every unit offer seven more candidates than that: 1760 instead of 1540 per query, and half of the queries
-  // needed a second staging round in the merge kernel.)
-  int kl;
-  {
-    const float share = (float)h.k / (float)ix.P;
-    kl = (int)(share + 5.0f * sqrtf(share) + 4.0f);
-    if (kl < k_local_floor) kl = k_local_floor;
-    if (kl > h.k) kl = h.k;
-    if (kl > SCAP - 32) kl = SCAP - 32;
-  }
+  // entries a unit must offer before it may withhold the rest (unit_kl), and the size up to which it simply offers
+  // everything
+  const int kl = unit_kl(h.k, ix.P, k_local_floor);
   const int keep_all = SCAP < kl + kl / 2 + 16 ? SCAP : kl + kl / 2 + 16;
-  // Cosine forms: a single-cluster candidate's key is a constant of its cluster, so WHERE to cut can be decided from
-  // the descriptors alone -- clusters by key, postings counted until kl are covered -- before a single posting has
-  // arrived: wave 0 does that in the shadow of the posting loads (5a'), and the data-dependent cut (5a) is skipped.
+  // Cosine forms: a single-cluster candidate's key is a constant of its cluster, so WHERE to cut was decided from the
+  // descriptors alone, by the descriptor kernel (unit_pre), and the data-dependent cut (5a) is skipped.
   const bool use_norms = NORMS && h.use_norms != 0;  // uniform
-  const bool pre_cut = (h.alg == 2 || h.alg == 4) && h.n_scan <= 64 && !overflow && !use_norms;  // uniform
+  const bool pre_cut = query_has_cluster_cut(h) && !overflow;  // uniform
+  const uint32_t pre_tau = pre_cut ? b.unit_pre[unit] : 0u;  // (uniform: a scalar load, long back when it is needed)
 
   // ---- 2. gather ---------------------------------------------------------------------------------------
   // A posting is looked at ONCE: window / source filters on its id, three Bloom bits from a hash of its id, and its
@@ -380,37 +417,6 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
         asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[u]) : "v"(src) : "memory");
       }
     STAMP(2);  // posting loads issued
-    if (pre_cut && tid < 64) {
-      // ---- 5a'. cluster-level cut (wave 0, while the loads are in flight) -----------------------------------------
-      // lane c = cluster c: its key with the low 8 bits replaced by c (keys 256 ulps apart tie; the cut is taken 256
-      // ulps low anyway), sorted descending; postings per cluster from the descriptors' prefix; the first cluster at
-      // which the running count reaches kl gives the cut.
-      const int lane = tid;
-      uint32_t pk = 0u;
-      if (lane < h.n_scan) {
-        const uint32_t kc = s_wkey[lane];
-        pk = kc ? ((kc & ~0xffu) | (uint32_t)lane) : 0u;
-      }
-      pk = wave_sort_desc_u32(pk);
-      const int c = (int)(pk & 0xffu);
-      int cum = 0;
-      if (pk) {
-        const uint32_t lo = s_pre[c], hi = (c + 1 < h.n_scan) ? s_pre[c + 1] : Tg;
-        cum = (int)((hi < Tg ? hi : Tg) - (lo < Tg ? lo : Tg));
-      }
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(cum, off, 64);
-        cum += lane >= off ? t : 0;
-      }
-      const unsigned long long ok = __ballot(pk != 0u && cum >= kl);
-      uint32_t tp = 0u;  // 0 = the unit's postings do not even add up to kl: keep everything
-      if (ok != 0ull) {
-        const uint32_t kc = s_wkey[__shfl(c, __ffsll((long long)ok) - 1, 64)];
-        tp = kc > 0x80000100u ? kc - 256u : kc;  // (256 ulps low: see 5a)
-      }
-      if (lane == 0) s_ctl[CTL_PRE] = (int)tp;
-    }
     if constexpr (U == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]) : : "memory");
     else if constexpr (U == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) : : "memory");
     else if constexpr (U == 6)
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   uint32_t *const s_lm = s_hist;  // [WG], in the dead Bloom filter's memory (or s_hist_own, which is WG <= 256 words)
   uint32_t tau = 0;  // survivors: k32 >= tau
   bool cut_by_data = !pre_cut;  // uniform
-  if (pre_cut && s_ctl[CTL_LIVE] > keep_all) tau = (uint32_t)s_ctl[CTL_PRE];
+  if (pre_cut && s_ctl[CTL_LIVE] > keep_all) tau = pre_tau;
   for (;;) {
     if (cut_by_data) {
       const bool select = s_ctl[CTL_LIVE] > keep_all && !overflow;  // uniform
@@ -886,7 +892,7 @@ static hipError_t launch_one(const IndexView &ix, const BatchView &b, const Fast
 // tables; the per-partition prefix over the clusters runs in LDS, and the rows are written out coalesced.  One
 // round of 1024 workgroups instead of four rounds of one-wave units, each a chain of three dependent trips to memory.
 constexpr int DESC_Q_ITEMS = 4096;  // NSCAN_MAX x 32
-__global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView b, int items_cap) {
+__global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView b, int items_cap, int k_local_floor) {
   // [c * P + p]; s_len becomes the exclusive prefix.  Sized by the launch for the batch's largest query (12.5 KB at
   // 50 clusters x 32 partitions): small enough to find room on a CU that is full of unit-kernel workgroups.
   extern __shared__ uint32_t s_desc[];
@@ -903,8 +909,25 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
   const int n_scan = b.hdr[q].n_scan;
   for (int p = tid; p < P; p += 256) b.unit_fb[(int64_t)q * P + p] = -1;
   if (n_scan > NSCAN_MAX) {  // the unit kernel sends such units to the general path
-    for (int p = tid; p < P; p += 256) b.unit_T[(int64_t)q * P + p] = 0;
+    for (int p = tid; p < P; p += 256) {
+      b.unit_T[(int64_t)q * P + p] = 0;
+      b.unit_pre[(int64_t)q * P + p] = 0u;
+    }
     return;
+  }
+  // cluster-level cut: the order of the query's clusters by key is the same for all of its units -- sorted once, by
+  // wave 0 (lane c = cluster c), while the other waves already chase the sub-list descriptors
+  __shared__ uint32_t s_okey[64];  // sorted position i: the cluster's key ...
+  __shared__ uint8_t s_ocl[64];    // ... and the cluster
+  const QueryHdr h = b.hdr[q];
+  const bool cluster_cut = query_has_cluster_cut(h);  // (uniform)
+  if (cluster_cut && tid < 64) {
+    const float inv_l2_32 = (float)(1.0 / h.l2norm);
+    const uint32_t kc = tid < n_scan ? cosine_cluster_key(h.alg, b.scan_w[scan_begin + tid], inv_l2_32) : 0u;
+    const uint32_t pk = wave_sort_desc_u32(kc ? ((kc & ~0xffu) | (uint32_t)tid) : 0u);
+    const int c = (int)(pk & 0xffu);
+    s_ocl[tid] = (uint8_t)c;
+    s_okey[tid] = pk ? __shfl(kc, c, 64) : 0u;
   }
   const uint32_t *cut = nullptr;  // cached cut table for this query's M, if any (uniform)
 #pragma unroll
@@ -928,6 +951,25 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
     s_len[i] = len;
   }
   __syncthreads();
+  if (cluster_cut) {
+    const int kl = unit_kl(h.k, P, k_local_floor);
+    for (int p = tid; p < P; p += 256) {  // clusters in key order until kl postings are covered
+      uint32_t pre = 0u;
+      int cum = 0;
+      for (int i = 0; i < n_scan; i++) {
+        const uint32_t kc = s_okey[i];
+        if (kc == 0u) break;  // (keys of 0 sort last: no trusted cluster is left)
+        cum += (int)s_len[(int)s_ocl[i] * P + p];
+        if (cum >= kl) {
+          pre = cluster_cut_from_key(kc);
+          break;
+        }
+      }
+      b.unit_pre[(int64_t)q * P + p] = pre;
+    }
+  } else {
+    for (int p = tid; p < P; p += 256) b.unit_pre[(int64_t)q * P + p] = 0u;
+  }
   for (int p = tid; p < P; p += 256) {  // exclusive prefix over the clusters, per partition
     uint32_t run = 0;
     for (int c = 0; c < n_scan; c++) {
@@ -946,14 +988,14 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
   }
 }
 
-hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int max_n_scan, hipStream_t stream) {
+hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int max_n_scan, int k_local_floor, hipStream_t stream) {
   if (n_units <= 0) return hipSuccess;
   const int items_cap = ix.P * (max_n_scan < NSCAN_MAX ? (max_n_scan > 0 ? max_n_scan : 1) : NSCAN_MAX);
   // (with fewer than 16 partitions a query has too few sub-lists to occupy a workgroup: 40 us against 33 at P = 8)
   if (ix.P >= 16 && ix.P * NSCAN_MAX <= DESC_Q_ITEMS)
-    hipLaunchKernelGGL(desc_query_kernel, dim3((unsigned)b.nq), dim3(256), (size_t)items_cap * 8, stream, ix, b, items_cap);
+    hipLaunchKernelGGL(desc_query_kernel, dim3((unsigned)b.nq), dim3(256), (size_t)items_cap * 8, stream, ix, b, items_cap, k_local_floor);
   else
-    hipLaunchKernelGGL(desc_kernel, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, ix, b, n_units);
+    hipLaunchKernelGGL(desc_kernel, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, ix, b, n_units, k_local_floor);
   return hipGetLastError();
 }
 

@@ -60,7 +60,7 @@ struct FastParams {
   int use_norms;      // some query of the batch scores with the index's norms column (offline forms)
 };
 hipError_t launch_cut(const IndexView &ix, int M, uint32_t *out, hipStream_t stream);
-hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int max_n_scan, hipStream_t stream);
+hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int max_n_scan, int k_local_floor, hipStream_t stream);
 hipError_t launch_unit_ablation(const IndexView &ix, const BatchView &b, const FastParams &fp, int abl, hipStream_t stream);
 hipError_t launch_unit_fast(const IndexView &ix, const BatchView &b, const FastParams &fp, int n_units,
                             hipStream_t stream);
