@@ -454,6 +454,19 @@ __device__ inline int run_count_before(const ulonglong2 *L, uint64_t xh, uint64_
   return pos + ((pos == 63 && before) ? 1 : 0);
 }
 
+// ... in a descending run of L entries, L a power of two (the pairwise merge rounds of the final sort)
+__device__ inline int run_count_before_n(const ulonglong2 *run, int L, uint64_t xh, uint64_t xl, bool ties_before) {
+  int pos = 0;
+  for (int step = L >> 1; step >= 1; step >>= 1) {
+    const ulonglong2 v = run[pos + step - 1];
+    const bool before = v.x > xh || (v.x == xh && (v.y > xl || (v.y == xl && ties_before)));
+    pos += before ? step : 0;
+  }
+  const ulonglong2 v = run[L - 1];
+  const bool before = v.x > xh || (v.x == xh && (v.y > xl || (v.y == xl && ties_before)));
+  return pos + ((pos == L - 1 && before) ? 1 : 0);
+}
+
 // The same for all the other runs of a sorted-runs array at once: the searches advance in lock step, so that every
 // step has one LDS read per run in flight instead of a chain of 7 x (runs - 1) dependent reads.
 template <int RMAX>
@@ -678,9 +691,12 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   }
 
   MSTAMP(4);  // compacted
-  // sort the survivors, keep the first k: every wave sorts runs of 64 in registers (DPP / permlane network, no barriers),
-  // the runs meet in LDS, and every entry finds its final position by binary searches in the other runs and goes
-  // straight to the output -- two barriers instead of the 45 barrier-separated stages of an LDS bitonic sort
+  // sort the survivors, keep the first k: every wave sorts runs of 64 in registers (DPP / permlane network, no barriers);
+  // the runs are then merged pairwise -- an entry's place in the merged pair is its offset in its own run plus the
+  // number of the partner run's entries that come before it, one binary search -- doubling the run length per round
+  // (two barriers each), and the last round writes straight to the output.  (An LDS bitonic sort of 512 took 45
+  // barrier-separated stages, 32 k clk; ranking every entry against ALL other runs at once was bound by LDS bandwidth,
+  // 24 k clk with four queries per CU.)
   uint64_t xk_hi = 0, xk_lo = 0;
   {
     int np = next_pow2(best_n);
@@ -691,32 +707,46 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
     const int R = np >> 6, lane = tid & 63, wv = tid >> 6;
     constexpr int PER = SURV / WG < 1 ? 1 : SURV / WG;
     uint64_t mh[PER], ml[PER];
+    int at[PER];  // the entry's current position in s_e2
 #pragma unroll
     for (int j = 0; j < PER; j++) {
       const int r = wv + j * (WG / 64);
       mh[j] = 0ull;
       ml[j] = 0ull;
+      at[j] = r * 64 + lane;
       if (r < R) {  // (uniform per wave)
-        const ulonglong2 v = s_e2[r * 64 + lane];
+        const ulonglong2 v = s_e2[at[j]];
         mh[j] = v.x;
         ml[j] = v.y;
         wave_sort_desc_k128(mh[j], ml[j]);
-        s_e2[r * 64 + lane] = make_ulonglong2(mh[j], ml[j]);
+        s_e2[at[j]] = make_ulonglong2(mh[j], ml[j]);
       }
     }
     __syncthreads();
     MSTAMP(5);  // runs sorted
+    for (int L = 64; L < np; L <<= 1) {  // (uniform)
+#pragma unroll
+      for (int j = 0; j < PER; j++) {
+        if (wv + j * (WG / 64) < R) {
+          const int base = at[j] & ~(2 * L - 1), off = at[j] & (L - 1);
+          const bool second = (at[j] & L) != 0;  // in the pair's second run: equal keys of the first run come before
+          at[j] = base + off + run_count_before_n(s_e2 + base + (second ? 0 : L), L, mh[j], ml[j], second);
+        }
+      }
+      if (2 * L >= np) break;  // merged completely: at[] is the rank
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < PER; j++)
+        if (wv + j * (WG / 64) < R) s_e2[at[j]] = make_ulonglong2(mh[j], ml[j]);
+      __syncthreads();
+    }
     const int cnt = best_n < k ? best_n : k;
 #pragma unroll
     for (int j = 0; j < PER; j++) {
-      const int r = wv + j * (WG / 64);
-      if (r < R) {
-        const int rank = rank_among_runs<(SURV + 63) / 64>(s_e2, R, r, lane, mh[j], ml[j]);
-        if (rank < cnt) {
-          out_ids[rank] = key_id(ml[j]);
-          out_scores[rank] = key_score(mh[j]);
-          if (rank == cnt - 1 && cnt == k) { s_mm[0] = mh[j]; s_mm[1] = ml[j]; }  // the k-th key
-        }
+      if (wv + j * (WG / 64) < R && at[j] < cnt) {
+        out_ids[at[j]] = key_id(ml[j]);
+        out_scores[at[j]] = key_score(mh[j]);
+        if (at[j] == cnt - 1 && cnt == k) { s_mm[0] = mh[j]; s_mm[1] = ml[j]; }  // the k-th key
       }
     }
     if (tid == 0) ((int32_t *)((char *)b.out_counts + out_shift))[ql] = cnt;
