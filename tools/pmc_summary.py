@@ -5,7 +5,7 @@ import sys
 from collections import defaultdict
 
 for d in sys.argv[1:]:
-    for path in glob.glob(d + "/*/*counter_collection.csv"):
+    for path in glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"):
         acc = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(path)):
             k = r["Kernel_Name"].split("(")[0][-40:]
