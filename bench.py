@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--e2e-steps", type=int, default=-1,
                     help="steps of the end-to-end leg: fresh queries every step through sann_get_tweet_candidates, host buffers in "
                          "and out (N = 1 only; -1 = as many as --steps, 0 = skip)")
-    ap.add_argument("--e2e-threads", type=int, default=3, help="concurrent callers of the end-to-end leg (the reference's callers are Finagle worker threads)")
+    ap.add_argument("--e2e-threads", type=int, default=4, help="concurrent callers of the end-to-end leg (the reference's callers are Finagle worker threads)")
     ap.add_argument("--e2e-query-sets", type=int, default=4, help="distinct query batches the end-to-end leg rotates through")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cpu_count, 16))")
     args = ap.parse_args()
