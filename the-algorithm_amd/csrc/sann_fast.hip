@@ -87,7 +87,12 @@ __device__ inline float approx_score(int alg, float d32, float n32, double nsq64
     case 3: {
       float l;
       if (n32 >= 1e-6f) {
-        l = log1pf(n32);
+        // log1p(x) = log(u) * x / (u - 1) with u = fl(1 + x): the quotient undoes the rounding of the sum, and log(u) is
+        // the hardware's v_log_f32 (1 ulp) -- a dozen issue slots where the library's log1pf took forty.  Audited, like
+        // everything here, by tests/test_sann_exactness_gpu.py::test_prefilter_error_bound.
+        const float u = 1.0f + n32;
+        const float dlt = u - 1.0f;  // (exact; > 0 for n32 >= 1e-6)
+        l = __logf(u) * (n32 * __builtin_amdgcn_rcpf(dlt));
       } else {
         const float x = (float)((1.0 + nsq64) - 1.0);
         *forced = !(x > 0.f);

@@ -12,9 +12,10 @@ pkg = ge.load_package()
 lib = pkg.load_library()
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
+ALG = {"cosine": "CosineSimilarity", "logcosine": "LogCosineSimilarity", "dot": "DotProduct"}[sys.argv[3] if len(sys.argv) > 3 else "cosine"]
 offs, cids, scs = pkg.corpus.make_queries(1024)
 index = pkg.ClusterTweetIndex.synthetic(T, n_partitions=P)
-cfg = pkg.SimClustersANNConfig(maxNumResults=400, annAlgorithm=pkg.ScoringAlgorithm.CosineSimilarity)
+cfg = pkg.SimClustersANNConfig(maxNumResults=400, annAlgorithm=getattr(pkg.ScoringAlgorithm, ALG))
 qb = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=pkg.corpus.NOW_MS)
 for _ in range(3):
     qb.run(); qb.finish()
