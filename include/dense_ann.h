@@ -45,6 +45,13 @@ const char *dann_last_error(void);
  * and <= 512.  Cosine stores L2-normalised vectors. */
 int dann_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
                      dann_index_t **out);
+/* The same, keeping the fp32 rows beside the fp16 ones (4 d bytes more per vector).  Searches on such an index score
+ * their survivors a second time from the fp32 rows -- fp32 operands (Cosine: normalised in fp32), fp32 accumulation, as
+ * BruteForceIndex.scala:66-91 does for every vector -- and prove, per query, that no vector the fp16 pass left out can
+ * reach the k-th fp32 score (else the pass repeats for that query with a lower threshold): results are those of an
+ * exact fp32 scan of the ORIGINAL vectors, up to the order of fp32 summation. */
+int dann_index_build_exact(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                           dann_index_t **out);
 /* Synthetic index generated on the device: i.i.d. N(0,1) components (BASELINE configs[3]: 50M x 256). */
 int dann_index_build_synthetic(int32_t device, int32_t metric, int64_t n, int32_t d, uint64_t seed, dann_index_t **out);
 /* The stored (fp16-rounded, for Cosine normalised) vectors [i0, i0+n) as fp32: audit / oracle input. */
@@ -56,6 +63,9 @@ int dann_index_destroy(dann_index_t *index);
  * Distances: L2 = ||q - x||, Cosine = 1 - cos(q, x), InnerProduct = 1 - <q, x>. */
 int dann_search(dann_index_t *index, int32_t nq, const float *queries, int32_t k, float *out_dist, int64_t *out_ids,
                 int32_t *out_counts);
+/* Full passes over the index the last dann_search needed: 1, plus one per round in which some query overflowed its
+ * survivor buffer or (exact mode) failed its completeness proof and was re-armed with a lower threshold. */
+int dann_last_rounds(const dann_index_t *index, int32_t *rounds);
 /* Milliseconds spent in the two GEMM passes and the selection of the last dann_search (HIP events). */
 int dann_last_timing(const dann_index_t *index, float *gemm_a_ms, float *gemm_b_ms, float *select_ms);
 

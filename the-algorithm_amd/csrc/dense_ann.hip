@@ -512,14 +512,19 @@ __device__ float wg_kth_largest(const float *vals, int64_t n, int stride, int k,
 }
 
 // tau[q] from the pass-A tile maxima; padded queries get +inf (never emit)
+// (exact mode: slack > 0 lowers tau by two rounding bounds, so that the vectors the fp32 re-rank could still prefer are
+// among the survivors from the first pass on; see prove_kernel)
 __global__ void tau_kernel(const float *__restrict__ tmax, int64_t pitch, int64_t n_tiles, int k, int nq,
-                           float *__restrict__ tau, uint32_t *__restrict__ cnt) {
+                           float *__restrict__ tau, uint32_t *__restrict__ cnt, const float *__restrict__ qsumsq, float slack_norm,
+                           int metric) {
   __shared__ uint32_t hist[258];
   int q = blockIdx.x;
   float v;
   if (q >= nq) v = INFINITY;
   else if (n_tiles < k) v = -INFINITY;
   else v = wg_kth_largest(tmax + (int64_t)q * pitch, n_tiles, 1, k, hist);
+  if (slack_norm > 0.0f && q < nq && v > -INFINITY)
+    v -= 2.0f * (slack_norm * sqrtf(qsumsq[q]) * 1.05e-3f + (metric == DANN_METRIC_L2 ? slack_norm * slack_norm * 5.0e-4f : 0.0f));
   if (threadIdx.x == 0) {
     tau[q] = v;
     cnt[q] = 0;
@@ -530,7 +535,7 @@ __global__ void tau_kernel(const float *__restrict__ tmax, int64_t pitch, int64_
 // status: 0 done, 1 redo, 2 cannot tighten (more than CAP scores tie at the k-th)
 __global__ void refine_kernel(float *__restrict__ tau, uint32_t *__restrict__ cnt, uint32_t *__restrict__ done_cnt,
                               const Survivor *__restrict__ surv, int k, int nq, int *__restrict__ status,
-                              int *__restrict__ flags) {
+                              int *__restrict__ flags, float *__restrict__ tau_used) {
   __shared__ uint32_t hist[258];
   int q = blockIdx.x;
   if (q >= nq) return;
@@ -540,6 +545,7 @@ __global__ void refine_kernel(float *__restrict__ tau, uint32_t *__restrict__ cn
     if (threadIdx.x == 0) {
       done_cnt[q] = c;
       status[q] = 0;
+      if (tau_used) tau_used[q] = tau[q];  // (exact mode: the threshold this query's survivors passed)
       tau[q] = INFINITY;
     }
     return;
@@ -611,6 +617,107 @@ __global__ __launch_bounds__(512) void select_kernel(const Survivor *__restrict_
   if (threadIdx.x == 0) out_counts[q] = (int32_t)m;
 }
 
+// ---- exact mode: the fp32 originals beside the fp16 fragments, and a re-rank of the survivors in fp32 ----------------
+// BruteForceIndex is an exact fp32 scan (ann/src/main/scala/com/twitter/ann/brute_force/BruteForceIndex.scala:66-91); the
+// fp16 GEMM decides which few thousand vectors per query are worth a second look, this scores them as the reference
+// would: fp32 operands (Cosine: normalised in fp32), fp32 accumulation.
+__global__ void store_rows_kernel(const float *__restrict__ src, int64_t n, int d, int normalise, int64_t row0,
+                                  float *__restrict__ x32, float *__restrict__ xss32) {
+  int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float *x = src + row * d;
+  double ss = 0;
+  for (int k = lane; k < d; k += 64) ss += (double)x[k] * (double)x[k];
+  ss = wave_sum(ss);
+  float norm = 1.0f;
+  if (normalise) {
+    norm = (float)sqrt(ss);
+    if (!(norm > 0.0f)) norm = 1.0f;
+  }
+  double ss2 = 0;
+  for (int k = lane; k < d; k += 64) {
+    const float v = x[k] / norm;
+    x32[(row0 + row) * d + k] = v;
+    ss2 += (double)v * (double)v;
+  }
+  ss2 = wave_sum(ss2);
+  if (lane == 0) xss32[row0 + row] = (float)ss2;
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  for (int o = 32; o; o >>= 1) v = v + __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one workgroup per query: every survivor's score again, from the fp32 rows
+__global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ q_in, int d, int metric, const float *__restrict__ x32,
+                                                      const float *__restrict__ xss32, Survivor *__restrict__ surv,
+                                                      const uint32_t *__restrict__ done_cnt, float *__restrict__ qsumsq) {
+  __shared__ float sq[MAX_D];
+  __shared__ double s_ss;
+  const int q = blockIdx.x, t = threadIdx.x;
+  double part = 0;
+  for (int k = t; k < d; k += 256) { const float v = q_in[(size_t)q * d + k]; part += (double)v * (double)v; }
+  part = wave_sum(part);
+  if (t == 0) s_ss = 0;
+  __syncthreads();
+  if ((t & 63) == 0) atomicAdd(&s_ss, part);
+  __syncthreads();
+  float norm = 1.0f;
+  if (metric == DANN_METRIC_COSINE) {
+    norm = (float)sqrt(s_ss);
+    if (!(norm > 0.0f)) norm = 1.0f;
+  }
+  double p2 = 0;
+  for (int k = t; k < d; k += 256) { const float v = q_in[(size_t)q * d + k] / norm; sq[k] = v; p2 += (double)v * (double)v; }
+  p2 = wave_sum(p2);
+  __syncthreads();
+  if (t == 0) s_ss = 0;
+  __syncthreads();
+  if ((t & 63) == 0) atomicAdd(&s_ss, p2);
+  __syncthreads();
+  if (t == 0) qsumsq[q] = (float)s_ss;  // |q|^2 of the fp32 query: what the L2 distance is rebuilt from
+  const uint32_t c = min(done_cnt[q], (uint32_t)CAP);
+  const int lane = t & 63, wv = t >> 6;
+  for (uint32_t i = wv; i < c; i += 4) {
+    Survivor s = surv[(size_t)q * CAP + i];
+    const float *x = x32 + (size_t)s.pos * d;
+    float acc = 0.0f;
+    for (int k = lane; k < d; k += 64) acc = acc + sq[k] * x[k];
+    acc = wave_sum_f32(acc);
+    if (metric == DANN_METRIC_L2) acc = acc - 0.5f * xss32[s.pos];
+    if (lane == 0) surv[(size_t)q * CAP + i].score = acc;
+  }
+}
+
+// A vector the fp16 pass did not emit has fp16-operand score < tau_used, hence fp32 score < tau_used + delta; it cannot
+// be among the k best if the k-th best rescored survivor is at least that.  delta bounds |fp32 score - fp16 score|:
+// operands rounded to 11 bits each (2^-10 |x||q| in all) plus the accumulation error of either sum, and for L2 the bias
+// -|x|^2/2 taken from the rounded row.  A query that fails the test is re-armed with a tau two deltas below its k-th.
+__global__ __launch_bounds__(256) void prove_kernel(const Survivor *__restrict__ surv, uint32_t *__restrict__ done_cnt,
+                                                    const float *__restrict__ tau_used, const float *__restrict__ qsumsq,
+                                                    float max_norm, int metric, int k, float *__restrict__ tau,
+                                                    uint32_t *__restrict__ cnt, int *__restrict__ status, int *__restrict__ flags) {
+  __shared__ uint32_t hist[258];
+  const int q = blockIdx.x;
+  const uint32_t c = min(done_cnt[q], (uint32_t)CAP);
+  if (c < (uint32_t)k) return;  // every stored vector was emitted (tau = -inf): nothing is hidden
+  const float kth = wg_kth_largest(&surv[(size_t)q * CAP].score, c, 2, k, hist);
+  if (threadIdx.x == 0) {
+    const float qn = sqrtf(qsumsq[q]);
+    const float delta = max_norm * qn * 1.05e-3f + (metric == DANN_METRIC_L2 ? max_norm * max_norm * 5.0e-4f : 0.0f);
+    const float used = tau_used[q];
+    if (used > -INFINITY && kth < used + delta) {
+      tau[q] = kth - 2.0f * delta;
+      cnt[q] = 0;
+      done_cnt[q] = 0xffffffffu;
+      status[q] = 1;
+      atomicOr(&flags[0], 1);
+    }
+  }
+}
+
 struct Buf {
   void *p = nullptr;
   size_t bytes = 0;
@@ -633,11 +740,14 @@ struct dann_index {
   int device = 0, metric = 0, d = 0, S = 0, VB = 0;
   int64_t n = 0, n_pad = 0;
   Buf xf, bias, ids;
-  bool has_ids = false;
+  Buf x32, xss32, tau_used;  // exact mode: fp32 rows [n][d] (Cosine: unit length), their squared norms, per-query thresholds
+  bool has_ids = false, exact = false;
+  float max_norm = 0.0f;     // exact mode: largest |x| of the stored rows
   // per-search scratch (grown on demand, reused)
   Buf q_in, qf, qsumsq, tmax, tau, cnt, done_cnt, surv, status, flags, o_dist, o_ids, o_cnt;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float t_a = 0, t_b = 0, t_sel = 0;
+  int last_rounds = 0;  // passes B of the last search (1 unless a query overflowed its buffer or, in exact mode, failed its proof)
   ~dann_index() {
     for (auto &e : ev)
       if (e) (void)hipEventDestroy(e);
@@ -701,8 +811,21 @@ extern "C" {
 
 const char *dann_last_error(void) { return g_err.c_str(); }
 
+static int build_impl(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids, bool exact,
+                      dann_index_t **out);
+
 int dann_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
                      dann_index_t **out) {
+  return build_impl(device, metric, n, d, vectors, ids, false, out);
+}
+
+int dann_index_build_exact(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                           dann_index_t **out) {
+  return build_impl(device, metric, n, d, vectors, ids, true, out);
+}
+
+static int build_impl(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids, bool exact,
+                      dann_index_t **out) {
   if (!vectors || !out) return fail(DANN_EINVAL, "null argument");
   std::unique_ptr<dann_index> ix(new dann_index);
   int rc = alloc_index(ix.get(), device, metric, n, d);
@@ -722,6 +845,10 @@ int dann_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const
   const int64_t chunk = std::max<int64_t>(1, (int64_t)(256u << 20) / ((int64_t)d * 4));
   Buf stage;
   DTRY(stage.reserve((size_t)std::min(chunk, n) * d * sizeof(float)));
+  if (exact) {
+    DTRY(ix->x32.reserve((size_t)n * d * sizeof(float)));
+    DTRY(ix->xss32.reserve((size_t)n * sizeof(float)));
+  }
   std::vector<float> gathered;
   for (int64_t r0 = 0; r0 < n; r0 += chunk) {
     int64_t m = std::min(chunk, n - r0);
@@ -736,7 +863,20 @@ int dann_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const
     hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, 0, stage.as<float>(), m, d, ix->S,
                        metric == DANN_METRIC_COSINE ? 1 : 0, r0, ix->xf.as<_Float16>(), ix->bias.as<float>());
     DTRY(hipGetLastError());
+    if (exact) {
+      hipLaunchKernelGGL(store_rows_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, 0, stage.as<float>(), m, d,
+                         metric == DANN_METRIC_COSINE ? 1 : 0, r0, ix->x32.as<float>(), ix->xss32.as<float>());
+      DTRY(hipGetLastError());
+    }
     DTRY(hipDeviceSynchronize());
+  }
+  if (exact) {
+    std::vector<float> ss((size_t)n);
+    DTRY(hipMemcpy(ss.data(), ix->xss32.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    float mx = 0.0f;
+    for (float v : ss) mx = std::max(mx, v);
+    ix->max_norm = std::sqrt(mx) * 1.0001f;
+    ix->exact = true;
   }
   hipLaunchKernelGGL(bias_kernel, dim3((unsigned)((ix->n_pad + 255) / 256)), dim3(256), 0, 0, ix->bias.as<float>(), n,
                      ix->n_pad, metric);
@@ -879,10 +1019,12 @@ static int search_chunk(dann_index_t *ix, int32_t nq, const float *queries, int3
     DTRY(hipGetLastError());
   }
   hipLaunchKernelGGL(tau_kernel, dim3(nq_pad), dim3(256), 0, st, ix->tmax.as<float>(), pitch, pitch, k, nq,
-                     ix->tau.as<float>(), ix->cnt.as<uint32_t>());
+                     ix->tau.as<float>(), ix->cnt.as<uint32_t>(), ix->qsumsq.as<float>(), ix->exact ? ix->max_norm : 0.0f, ix->metric);
   DTRY(hipGetLastError());
   DTRY(hipEventRecord(ix->ev[1], st));
 
+  if (ix->exact) DTRY(ix->tau_used.reserve((size_t)nq_pad * sizeof(float)));
+  float *const d_tau_used = ix->exact ? ix->tau_used.as<float>() : nullptr;
   int flags = 0;
   for (int round = 0;; ++round) {
     if (n_full) {
@@ -902,14 +1044,38 @@ static int search_chunk(dann_index_t *ix, int32_t nq, const float *queries, int3
     if (round == 0) DTRY(hipEventRecord(ix->ev[2], st));
     DTRY(hipMemsetAsync(ix->flags.p, 0, sizeof(int), st));
     hipLaunchKernelGGL(refine_kernel, dim3(nq), dim3(256), 0, st, ix->tau.as<float>(), ix->cnt.as<uint32_t>(),
-                       ix->done_cnt.as<uint32_t>(), ix->surv.as<Survivor>(), k, nq, ix->status.as<int>(), ix->flags.as<int>());
+                       ix->done_cnt.as<uint32_t>(), ix->surv.as<Survivor>(), k, nq, ix->status.as<int>(), ix->flags.as<int>(),
+                       d_tau_used);
     DTRY(hipGetLastError());
     DTRY(hipMemcpyAsync(&flags, ix->flags.p, sizeof(int), hipMemcpyDeviceToHost, st));
     DTRY(hipStreamSynchronize(st));
     if (flags & 2) return fail(DANN_ELIMIT, "more than 8192 stored vectors tie at the k-th distance of a query");
-    if (!(flags & 1)) break;
     if (round >= 16) return fail(DANN_ELIMIT, "threshold refinement did not converge");
+    if (flags & 1) {
+      continue;
+    }
+    if (!ix->exact) {
+      ix->last_rounds = round + 1;
+      break;
+    }
+    // exact mode: survivors scored again in fp32, then the proof that nothing below the fp16 threshold could matter
+    hipLaunchKernelGGL(rescore_kernel, dim3(nq), dim3(256), 0, st, ix->q_in.as<float>(), d, ix->metric, ix->x32.as<float>(),
+                       ix->xss32.as<float>(), ix->surv.as<Survivor>(), ix->done_cnt.as<uint32_t>(), ix->qsumsq.as<float>());
+    DTRY(hipGetLastError());
+    DTRY(hipMemsetAsync(ix->flags.p, 0, sizeof(int), st));
+    const float delta_scale = getenv("DANN_DEBUG_DELTA_SCALE") ? (float)atof(getenv("DANN_DEBUG_DELTA_SCALE")) : 1.0f;  // tests: force the re-arm path
+    hipLaunchKernelGGL(prove_kernel, dim3(nq), dim3(256), 0, st, ix->surv.as<Survivor>(), ix->done_cnt.as<uint32_t>(), d_tau_used,
+                       ix->qsumsq.as<float>(), ix->max_norm * delta_scale, ix->metric, k, ix->tau.as<float>(), ix->cnt.as<uint32_t>(),
+                       ix->status.as<int>(), ix->flags.as<int>());
+    DTRY(hipGetLastError());
+    DTRY(hipMemcpyAsync(&flags, ix->flags.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    DTRY(hipStreamSynchronize(st));
+    if (!(flags & 1)) {  // every query proven
+      ix->last_rounds = round + 1;
+      break;
+    }
   }
+
   DTRY(hipFuncSetAttribute((const void *)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                            CAP * sizeof(unsigned long long)));
   hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(512), CAP * sizeof(unsigned long long), st, ix->surv.as<Survivor>(),
@@ -924,6 +1090,12 @@ static int search_chunk(dann_index_t *ix, int32_t nq, const float *queries, int3
   (void)hipEventElapsedTime(&ix->t_a, ix->ev[0], ix->ev[1]);
   (void)hipEventElapsedTime(&ix->t_b, ix->ev[1], ix->ev[2]);
   (void)hipEventElapsedTime(&ix->t_sel, ix->ev[2], ix->ev[3]);
+  return DANN_OK;
+}
+
+int dann_last_rounds(const dann_index_t *ix, int32_t *rounds) {
+  if (!ix || !rounds) return fail(DANN_EINVAL, "null argument");
+  *rounds = ix->last_rounds;
   return DANN_OK;
 }
 

@@ -31,10 +31,12 @@ class DistanceMetric(enum.IntEnum):
 PROTOS = {
     "dann_last_error": (C.c_char_p, []),
     "dann_index_build": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dann_index_build_exact": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "dann_index_build_synthetic": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
     "dann_index_get_vectors": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "dann_index_destroy": (C.c_int, [C.c_void_p]),
     "dann_search": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dann_last_rounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "dann_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 
@@ -67,7 +69,9 @@ class BruteForceIndex:
         self._h, self.metric, self.n, self.d = handle, DistanceMetric(metric), n, d
 
     @classmethod
-    def build(cls, metric: DistanceMetric, vectors: np.ndarray, ids: Optional[Sequence[int]] = None, *, device: int = 0):
+    def build(cls, metric: DistanceMetric, vectors: np.ndarray, ids: Optional[Sequence[int]] = None, *, device: int = 0,
+              exact: bool = False):
+        """exact=True keeps the fp32 rows and re-ranks every search's survivors in fp32 (dann_index_build_exact)."""
         lib = _lib()
         v = np.ascontiguousarray(vectors, np.float32)
         if v.ndim != 2:
@@ -78,8 +82,9 @@ class BruteForceIndex:
             if idp.shape != (v.shape[0],):
                 raise ValueError("one id per vector")
         h = C.c_void_p()
-        _check(lib, lib.dann_index_build(device, int(metric), v.shape[0], v.shape[1], v.ctypes.data,
-                                         idp.ctypes.data if idp is not None else None, C.byref(h)))
+        fn = lib.dann_index_build_exact if exact else lib.dann_index_build
+        _check(lib, fn(device, int(metric), v.shape[0], v.shape[1], v.ctypes.data,
+                       idp.ctypes.data if idp is not None else None, C.byref(h)))
         return cls(h, metric, v.shape[0], v.shape[1])
 
     @classmethod
@@ -96,6 +101,12 @@ class BruteForceIndex:
         lib = _lib()
         _check(lib, lib.dann_index_get_vectors(self._h, i0, n, out.ctypes.data))
         return out
+
+    def last_rounds(self) -> int:
+        r = C.c_int32()
+        lib = _lib()
+        _check(lib, lib.dann_last_rounds(self._h, C.byref(r)))
+        return r.value
 
     def search(self, queries: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """Batched queryWithDistance: (ids [nq, k], distances [nq, k], counts [nq]), ascending by distance."""
