@@ -57,7 +57,8 @@ constexpr int CCAP_LDS = 2048;   // candidate queue entries in LDS
 constexpr int CCAP_LDS_BIG = 16384;  // last LDS tier of a query that overflowed the smaller ones: 136 KB of LDS, one wave per CU
 // LDS tiers of the candidate queue.  A query that outgrows one is run again in the next (the walk is the same, only the
 // capacity differs); the index remembers, per beam width, the largest queue the previous search saw and starts there.
-constexpr int CCAP_TIERS[] = {CCAP_LDS, 4096, 8192, CCAP_LDS_BIG};
+constexpr int CCAP_TIERS[] = {512, 1024, CCAP_LDS, 4096, 8192, CCAP_LDS_BIG};
+constexpr int N_CCAP_TIERS = 6;
 constexpr int CCAP_GLOBAL = 1 << 17;
 
 struct Buf {
@@ -172,7 +173,7 @@ struct SearchArgs {
   int64_t *out_ids;
   int32_t *out_counts;
   int32_t *spill;             // [nq] set when the LDS candidate queue overflowed
-  unsigned long long *stats;  // [0] distance evaluations, [1] expansions, [2] largest candidate queue, [3..7] queries by the tier that fits them
+  unsigned long long *stats;  // [0] distance evaluations, [1] expansions, [2] largest candidate queue, [3..9] queries by the tier that fits them
   int64_t vwords;
   int32_t dpad, chunks, m, m0, metric, k, ef, max_level;
   int32_t ccap_lds;           // candidate-queue entries allowed in LDS (<= CCAP_LDS; smaller only for tests)
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
     atomicMax(&a.stats[2], (unsigned long long)(overflow ? ccap + 1 : peak));  // largest candidate queue of the launch
     if (!overflow) {  // (a query finishes exactly once) which LDS tier would have been enough for it
       int t = 0;
-      while (t < 4 && peak > CCAP_TIERS[t]) ++t;
+      while (t < N_CCAP_TIERS && peak > CCAP_TIERS[t]) ++t;
       atomicAdd(&a.stats[3 + t], 1ull);
     }
   }
@@ -1018,13 +1019,13 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   HTRY(ix->o_ids.reserve((size_t)nq * k * 8));
   HTRY(ix->o_cnt.reserve((size_t)nq * 4));
   HTRY(ix->spill.reserve((size_t)nq * 4));
-  HTRY(ix->stats.reserve(64));
+  HTRY(ix->stats.reserve(128));
   hipStream_t st = 0;
   HTRY(hipMemcpyAsync(ix->q_in.p, queries, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(hnsw_prep_rows, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, ix->q_in.as<float>(), (int64_t)nq, ix->d,
                      ix->dpad, ix->metric == HNSW_METRIC_COSINE ? 1 : 0, ix->q.as<_Float16>());
   HTRY(hipGetLastError());
-  HTRY(hipMemsetAsync(ix->stats.p, 0, 64, st));
+  HTRY(hipMemsetAsync(ix->stats.p, 0, 128, st));
   HTRY(hipMemsetAsync(ix->spill.p, 0, (size_t)nq * 4, st));
 
   SearchArgs a;
@@ -1064,8 +1065,13 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
     if (v < 0) tier_cap[n_lds_tiers++] = CCAP_LDS_BIG;
     skip_mid = true;
   } else {
-    // start at the smallest tier that held nine tenths of the queries of the last search with this beam width
-    const int t0 = ix->tier_hint[beam] > 0 ? ix->tier_hint[beam] - 1 : 0;
+    // start at the smallest tier that held nine tenths of the queries of the last search with this beam width; without
+    // history, at the first tier of at least 2.5 beams (the queue reaches 2-3x the beam on clustered data).  Small tiers
+    // matter for small beams: at ef = 100 the 2048-entry tier's 16 KB allowed 9 walks per CU, 512 entries allow 32.
+    int t0 = 0;
+    if (ix->tier_hint[beam] > 0) t0 = ix->tier_hint[beam] - 1;
+    else
+      while (t0 < N_TIERS - 1 && CCAP_TIERS[t0] < beam * 5 / 2) ++t0;
     for (int t = t0; t < N_TIERS; ++t) tier_cap[n_lds_tiers++] = CCAP_TIERS[t];
   }
   (void)skip_mid;
@@ -1131,8 +1137,8 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   }
   if (!redo.empty()) return fail(HNSW_ELIMIT, "candidate queue above 131072 entries");
   HTRY(hipEventRecord(ix->ev[1], st));
-  unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  HTRY(hipMemcpyAsync(stats, ix->stats.p, 64, hipMemcpyDeviceToHost, st));
+  unsigned long long stats[16] = {0};
+  HTRY(hipMemcpyAsync(stats, ix->stats.p, 128, hipMemcpyDeviceToHost, st));
   HTRY(hipMemcpyAsync(out_dist, ix->o_dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
   HTRY(hipMemcpyAsync(out_ids, ix->o_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
   HTRY(hipMemcpyAsync(out_counts, ix->o_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
@@ -1143,7 +1149,7 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   if (!getenv("HNSW_DEBUG_CCAP")) {
     unsigned long long cum = 0;
     int t = 0;
-    for (; t < 3; ++t) {
+    for (; t < N_CCAP_TIERS - 1; ++t) {
       cum += stats[3 + t];
       if (cum * 10 >= (unsigned long long)nq * 9) break;
     }
