@@ -103,10 +103,11 @@ def main():
     sharded = world > 1 or args.exercise_exchange
     dist = torch = None
     json_fd = None
-    if sharded and args.backend != "gloo":
+    if sharded:
         # RCCL prints a version banner on STDOUT when the first communicator of the process comes up (through torch's
-        # process group or through the library's own).  This program's stdout is ONE JSON line: file descriptor 1 is
-        # pointed at stderr for the rest of the run and the JSON line goes to a private copy of the original.
+        # process group or through the library's own), and so does gloo ("[Gloo] Rank 0 is connected to ...").  This
+        # program's stdout is ONE JSON line: file descriptor 1 is pointed at stderr for the rest of the run and the JSON
+        # line goes to a private copy of the original.
         sys.stdout.flush()
         json_fd = os.dup(1)
         os.dup2(2, 1)
