@@ -69,6 +69,16 @@ int hnsw_index_build_insert(int32_t device, int32_t metric, int64_t n, int32_t d
 int hnsw_index_build_insert_levels(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors,
                                    const int64_t *ids, int32_t max_m, int32_t ef_construction, const int32_t *levels,
                                    int32_t n_threads, hnsw_index_t **out);
+/* Build on the device: the items of the upper layers are inserted on the host as above (they fix the entry point and every
+ * layer above 0); all others -- which only ever touch layer 0 -- go in in batches on the GPU: a batch searches one
+ * snapshot of the graph with beam ef_construction (the walk kernel), every item selects its neighbours by the
+ * reference's heuristic, and the back links are applied per target node by one wave (append while the list has room,
+ * else re-select by the heuristic, HnswIndex.java:414-427).  This is the reference's multi-writer mode taken wide: items
+ * of one batch do not see each other, so the graph is not the sequential one ("when using concurrent writers we can miss
+ * connections", :376-380); its quality is what recall against the exhaustive search says.  ef_construction <= 256;
+ * batch = items per round (0 = 4096). */
+int hnsw_index_build_insert_gpu(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                                int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t batch, hnsw_index_t **out);
 int hnsw_index_graph_size(const hnsw_index_t *index, int64_t *n_entries, int64_t *n_neighbours, int64_t *entry_point,
                           int32_t *max_level);
 int hnsw_index_graph(const hnsw_index_t *index, int32_t *entry_level, int64_t *entry_item, int64_t *entry_offsets,

@@ -379,6 +379,182 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batched index construction on the device (hnsw_index_build_insert_gpu).
+//
+// The reference inserts one item at a time, and with several writer threads it accepts what that costs: "when using
+// concurrent writers we can miss connections that we would otherwise get" (HnswIndex.java:376-380).  The device
+// builder is that mode taken wide: a batch of items searches one snapshot of the graph (the walk kernel above, with
+// beam efConstruction), every item picks its neighbours by the reference's heuristic
+// (selectNearestNeighboursByHeuristic, :479-526), and the back links are applied per TARGET node -- all additions to one
+// node by one wave, which appends while the list has room (:414-417) and otherwise re-selects by the same heuristic over
+// the old list plus the additions (:419-427) -- so no two waves ever write one list and nothing needs a lock.  Items of
+// one batch do not see each other; the graph is therefore not the sequential one (nor is the reference's with two
+// writers), and its quality is checked the way such a graph can be: recall against the exhaustive search.
+// One wave per task.  Task = (base node, candidate list): candidates ascending by distance to the base.
+// ---------------------------------------------------------------------------------------------
+struct LinkArgs {
+  const _Float16 *x;
+  uint32_t *adj0;              // [n][m0 + 1], updated in place
+  int32_t dpad, chunks, metric, m0;
+  // mode 0: new items.  base = targets[task]; candidates = the walk's results (positions, ascending)
+  const int64_t *cand_ids;     // [tasks][cand_stride]
+  const float *cand_dist;
+  const int32_t *cand_cnt;
+  int32_t cand_stride, max_keep;
+  uint32_t first_item;
+  uint32_t *sel;               // [tasks][max_keep + 1]: count, chosen neighbours (for the host's grouping)
+  // mode 1: back links.  base = targets[task]; additions[add_off[task] .. add_off[task+1])
+  const uint32_t *targets;
+  const uint32_t *add_off;
+  const uint32_t *additions;
+};
+
+// distance between stored rows a and b by the 8 lanes of a group (j = lane & 7), the walk's arithmetic; every lane of
+// the group returns the sum
+template <int CH>
+__device__ __forceinline__ float group_row_distance(const LinkArgs &a, uint32_t ra, uint32_t rb, int j) {
+  const half8 *pa = (const half8 *)(a.x + (size_t)ra * a.dpad), *pb = (const half8 *)(a.x + (size_t)rb * a.dpad);
+  float acc = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const half8 va = pa[j + 8 * c], vb = pb[j + 8 * c];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float fa = (float)va[e], fb = (float)vb[e];
+      if (a.metric == HNSW_METRIC_L2) {
+        const float t = fa - fb;
+        acc = acc + t * t;
+      } else {
+        acc = acc + fa * fb;
+      }
+    }
+  }
+  acc = acc + __shfl_xor(acc, 1, 64);
+  acc = acc + __shfl_xor(acc, 2, 64);
+  acc = acc + __shfl_xor(acc, 4, 64);
+  return finish_distance(a.metric, acc);
+}
+
+constexpr int LINK_CAND = 256;  // candidates a task can hold (efConstruction <= 256; a target's old list + additions <= 192)
+
+template <int CH, int MODE>
+__global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
+  __shared__ uint32_t c_id[LINK_CAND];
+  __shared__ float c_d[LINK_CAND];
+  __shared__ uint32_t t_id[LINK_CAND];
+  __shared__ float t_d[LINK_CAND];
+  __shared__ uint32_t kept[2 * MAX_M];
+  const int lane = threadIdx.x, g = lane >> 3, j = lane & 7;
+  const int task = blockIdx.x;
+  uint32_t base;
+  int n = 0, max_keep;
+  if (MODE == 0) {
+    base = a.targets[task];
+    max_keep = a.max_keep;
+    n = a.cand_cnt[task];
+    n = n < LINK_CAND ? n : LINK_CAND;
+    for (int i = lane; i < n; i += 64) {
+      c_id[i] = (uint32_t)a.cand_ids[(size_t)task * a.cand_stride + i];
+      c_d[i] = a.cand_dist[(size_t)task * a.cand_stride + i];
+    }
+    __syncthreads();
+  } else {
+    base = a.targets[task];
+    max_keep = a.m0;
+    uint32_t *row = a.adj0 + (size_t)base * (a.m0 + 1);
+    const int old_n = (int)row[0];
+    const int add_n = (int)(a.add_off[task + 1] - a.add_off[task]);
+    if (old_n + add_n <= a.m0) {  // room: append (:414-417)
+      for (int i = lane; i < add_n; i += 64) row[1 + old_n + i] = a.additions[a.add_off[task] + i];
+      __syncthreads();
+      if (lane == 0) row[0] = (uint32_t)(old_n + add_n);
+      return;
+    }
+    n = old_n + add_n;
+    n = n < LINK_CAND ? n : LINK_CAND;
+    for (int i = lane; i < n; i += 64) t_id[i] = i < old_n ? row[1 + i] : a.additions[a.add_off[task] + (i - old_n)];
+    __syncthreads();
+    // distances to the base, eight candidates per round
+    for (int i0 = 0; i0 < n; i0 += 8) {
+      const int i = i0 + g;
+      float d = 0.0f;
+      if (i < n) d = group_row_distance<CH>(a, base, t_id[i], j);
+      if (i < n && j == 0) t_d[i] = d;
+    }
+    __syncthreads();
+    // ascending by (distance, position): every lane ranks its candidates by counting
+    for (int i = lane; i < n; i += 64) {
+      const float d = t_d[i];
+      int rank = 0;
+      for (int e = 0; e < n; ++e) {
+        const float o = t_d[e];
+        rank += (o < d || (o == d && e < i)) ? 1 : 0;
+      }
+      c_id[rank] = t_id[i];
+      c_d[rank] = d;
+    }
+    __syncthreads();
+  }
+  // ---- selectNearestNeighboursByHeuristic: closest first; a candidate is dropped if some kept node is closer to it
+  //      than the base is (:508-519) -------------------------------------------------------------------------------
+  int nk = 0;
+  if (n <= max_keep) {  // (:488-491) everything, except the base itself
+    for (int i = 0; i < n; ++i)
+      if (c_id[i] != base) {
+        if (lane == 0) kept[nk] = c_id[i];
+        nk++;
+      }
+  } else {
+    for (int i = 0; i < n && nk < max_keep; ++i) {
+      const uint32_t c = c_id[i];
+      if (c == base) continue;
+      const float dc = c_d[i];
+      bool drop = false;
+      for (int k0 = 0; k0 < nk && !drop; k0 += 8) {
+        const int k = k0 + g;
+        bool closer = false;
+        if (k < nk) closer = group_row_distance<CH>(a, kept[k], c, j) < dc;
+        drop = __ballot(closer) != 0ull;
+      }
+      if (!drop) {
+        if (lane == 0) kept[nk] = c;
+        nk++;
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t *row = a.adj0 + (size_t)base * (a.m0 + 1);
+  for (int i = lane; i < nk; i += 64) row[1 + i] = kept[i];
+  if (lane == 0) row[0] = (uint32_t)nk;
+  if (MODE == 0) {
+    uint32_t *s = a.sel + (size_t)task * (a.max_keep + 1);
+    for (int i = lane; i < nk; i += 64) s[1 + i] = kept[i];
+    if (lane == 0) s[0] = (uint32_t)nk;
+  }
+}
+
+template <int CH>
+int launch_link(int mode, int tasks, const LinkArgs &a, hipStream_t st) {
+  if (tasks <= 0) return HNSW_OK;
+  if (mode == 0) hipLaunchKernelGGL((hnsw_link_kernel<CH, 0>), dim3(tasks), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL((hnsw_link_kernel<CH, 1>), dim3(tasks), dim3(64), 0, st, a);
+  return HNSW_OK;
+}
+int launch_link_any(int chunks, int mode, int tasks, const LinkArgs &a, hipStream_t st) {
+  switch (chunks) {
+    case 1: return launch_link<1>(mode, tasks, a, st);
+    case 2: return launch_link<2>(mode, tasks, a, st);
+    case 3: return launch_link<3>(mode, tasks, a, st);
+    case 4: return launch_link<4>(mode, tasks, a, st);
+    case 5: return launch_link<5>(mode, tasks, a, st);
+    case 6: return launch_link<6>(mode, tasks, a, st);
+    case 7: return launch_link<7>(mode, tasks, a, st);
+    default: return launch_link<8>(mode, tasks, a, st);
+  }
+}
+
 // rows (fp32) -> fp16 rows padded to dpad; Cosine rows are normalised first (Hnsw.scala:149-155)
 __global__ void hnsw_prep_rows(const float *__restrict__ src, int64_t n, int d, int dpad, int normalise,
                                _Float16 *__restrict__ dst) {
@@ -905,6 +1081,176 @@ static int build_insert_impl(int32_t device, int32_t metric, int64_t n, int32_t 
   }
   rc = upload_graph(ix.get(), g);
   if (rc) return rc;
+  *out = ix.release();
+  return HNSW_OK;
+}
+
+// Construction on the device.  Items with a level above 0 (one in maxM) go in first, on the host, one by one as
+// the reference does -- that fixes the entry point and every upper layer -- and the rest, which only ever touch layer 0,
+// in batches on the GPU (see hnsw_link_kernel).  batch = items per round (0 = 4096; a round never holds more than an
+// eighth of the graph it searches, so early rounds are small).
+int hnsw_index_build_insert_gpu(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                                int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t batch, hnsw_index_t **out) {
+  if (!out) return fail(HNSW_EINVAL, "out is NULL");
+  if (ef_construction < 1 || ef_construction > LINK_CAND) return fail(HNSW_EINVAL, "ef_construction must be in 1..256");
+  if (batch < 0) return fail(HNSW_EINVAL, "batch must not be negative");
+  if (batch == 0) batch = 4096;
+  std::unique_ptr<hnsw_index> ix;
+  std::vector<float> rows;
+  int rc = create_index(device, metric, n, d, vectors, nullptr, max_m, ix, &rows);  // (positions as labels while building)
+  if (rc) return rc;
+  const double level_mult = 1.0 / std::log(1.0 * max_m);  // HnswIndex.java:118
+  std::vector<int32_t> levels((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t h = sann::mix64(seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull));
+    const double u = ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740992.0);  // (0, 1]
+    levels[(size_t)i] = std::min(60, (int)(-std::log(u) * level_mult));       // getRandomLevel, :369-371
+  }
+  // ---- host: the items of the upper layers, and enough of the others for the first device rounds to have a graph -----
+  HostGraph g;
+  g.init(n, max_m, levels);
+  HostVectors hv;
+  hv.load(rows, n, ix->dpad, metric);
+  rows.clear();
+  rows.shrink_to_fit();
+  std::vector<uint8_t> done((size_t)n, 0);
+  {
+    std::vector<uint32_t> first;
+    for (int64_t i = 0; i < n; ++i)
+      if (levels[(size_t)i] > 0) { first.push_back((uint32_t)i); done[(size_t)i] = 1; }
+    for (int64_t i = 0; i < n && (int64_t)first.size() < std::min<int64_t>(n, 1024); ++i)
+      if (!done[(size_t)i]) { first.push_back((uint32_t)i); done[(size_t)i] = 1; }
+    // (as hnsw_index_build_insert: the first few one by one, the rest by a pool of writers under per-item locks)
+    const size_t warm = std::min<size_t>(first.size(), 256);
+    {
+      Builder b{g, hv, ef_construction, std::vector<uint32_t>((size_t)n, 0), 0};
+      for (size_t t = 0; t < warm; ++t) b.insert(first[t], levels[(size_t)first[t]]);
+    }
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())),
+                                                            (first.size() - warm) / 64));
+    std::atomic<size_t> next(warm);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt && warm < first.size(); ++t)
+      pool.emplace_back([&]() {
+        Builder b{g, hv, ef_construction, std::vector<uint32_t>((size_t)n, 0), 0};
+        for (;;) {
+          const size_t e = next.fetch_add(1);
+          if (e >= first.size()) break;
+          b.insert(first[e], levels[(size_t)first[e]]);
+        }
+      });
+    for (auto &th : pool) th.join();
+  }
+  rc = upload_graph(ix.get(), g);
+  if (rc) return rc;
+  // ---- device: the rest, layer 0 only, in rounds ---------------------------------------------------------------------
+  std::vector<uint32_t> todo;
+  for (int64_t i = 0; i < n; ++i)
+    if (!done[(size_t)i]) todo.push_back((uint32_t)i);
+  int64_t in_graph = n - (int64_t)todo.size();
+  HTRY(hipSetDevice(device));
+  const int k_walk = ef_construction;
+  Buf d_sel, d_targets, d_addoff, d_adds, d_cand_ids, d_cand_dist, d_cand_cnt;
+  std::vector<float> q, w_dist;
+  std::vector<int64_t> w_ids;
+  std::vector<int32_t> w_cnt;
+  std::vector<uint32_t> sel, targets, add_off, adds;
+  std::vector<std::pair<uint32_t, uint32_t>> pairs;  // (target, new item)
+  size_t at = 0;
+  while (at < todo.size()) {
+    const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(batch, in_graph / 8));
+    const size_t m = (size_t)std::min<int64_t>(cap, (int64_t)(todo.size() - at));
+    // the round's items as queries (their original rows: hnsw_search prepares them exactly as the stored ones were)
+    q.resize(m * (size_t)d);
+    for (size_t t = 0; t < m; ++t) std::memcpy(&q[t * d], vectors + (size_t)todo[at + t] * d, (size_t)d * sizeof(float));
+    w_dist.resize(m * (size_t)k_walk);
+    w_ids.resize(m * (size_t)k_walk);
+    w_cnt.resize(m);
+    rc = hnsw_search(ix.get(), (int32_t)m, q.data(), k_walk, ef_construction, w_dist.data(), w_ids.data(), w_cnt.data());
+    if (rc) return rc;
+    // items are not contiguous in position: the link kernel takes explicit bases through a one-entry "targets" list
+    HTRY(d_cand_ids.reserve(m * (size_t)k_walk * 8));
+    HTRY(d_cand_dist.reserve(m * (size_t)k_walk * 4));
+    HTRY(d_cand_cnt.reserve(m * 4));
+    HTRY(hipMemcpy(d_cand_ids.p, w_ids.data(), m * (size_t)k_walk * 8, hipMemcpyHostToDevice));
+    HTRY(hipMemcpy(d_cand_dist.p, w_dist.data(), m * (size_t)k_walk * 4, hipMemcpyHostToDevice));
+    HTRY(hipMemcpy(d_cand_cnt.p, w_cnt.data(), m * 4, hipMemcpyHostToDevice));
+    HTRY(d_targets.reserve(std::max<size_t>(m, 1) * 4));
+    HTRY(hipMemcpy(d_targets.p, todo.data() + at, m * 4, hipMemcpyHostToDevice));
+    HTRY(d_sel.reserve(m * (size_t)(max_m + 1) * 4));
+    LinkArgs a;
+    a.x = ix->x.as<_Float16>();
+    a.adj0 = ix->adj0.as<uint32_t>();
+    a.dpad = ix->dpad;
+    a.chunks = ix->dpad / 64;
+    a.metric = ix->metric;
+    a.m0 = ix->m0;
+    a.cand_ids = d_cand_ids.as<int64_t>();
+    a.cand_dist = d_cand_dist.as<float>();
+    a.cand_cnt = d_cand_cnt.as<int32_t>();
+    a.cand_stride = k_walk;
+    a.max_keep = max_m;  // (:392: maxM for the new item on every level)
+    a.first_item = 0;
+    a.sel = d_sel.as<uint32_t>();
+    a.targets = d_targets.as<uint32_t>();
+    a.add_off = nullptr;
+    a.additions = nullptr;
+    rc = launch_link_any(a.chunks, 0, (int)m, a, 0);
+    if (rc) return rc;
+    HTRY(hipGetLastError());
+    sel.resize(m * (size_t)(max_m + 1));
+    HTRY(hipMemcpy(sel.data(), d_sel.p, sel.size() * 4, hipMemcpyDeviceToHost));
+    // back links grouped by target: one wave per target applies all of them
+    pairs.clear();
+    for (size_t t = 0; t < m; ++t) {
+      const uint32_t *row = &sel[t * (size_t)(max_m + 1)];
+      for (uint32_t e = 0; e < row[0]; ++e) pairs.emplace_back(row[1 + e], todo[at + t]);
+    }
+    std::sort(pairs.begin(), pairs.end());
+    targets.clear();
+    add_off.assign(1, 0);
+    adds.clear();
+    for (size_t e = 0; e < pairs.size(); ++e) {
+      if (e == 0 || pairs[e].first != pairs[e - 1].first) {
+        if (e) add_off.push_back((uint32_t)adds.size());
+        targets.push_back(pairs[e].first);
+      }
+      adds.push_back(pairs[e].second);
+    }
+    add_off.push_back((uint32_t)adds.size());
+    if (!targets.empty()) {
+      HTRY(d_targets.reserve(targets.size() * 4));
+      HTRY(d_addoff.reserve(add_off.size() * 4));
+      HTRY(d_adds.reserve(adds.size() * 4));
+      HTRY(hipMemcpy(d_targets.p, targets.data(), targets.size() * 4, hipMemcpyHostToDevice));
+      HTRY(hipMemcpy(d_addoff.p, add_off.data(), add_off.size() * 4, hipMemcpyHostToDevice));
+      HTRY(hipMemcpy(d_adds.p, adds.data(), adds.size() * 4, hipMemcpyHostToDevice));
+      a.targets = d_targets.as<uint32_t>();
+      a.add_off = d_addoff.as<uint32_t>();
+      a.additions = d_adds.as<uint32_t>();
+      rc = launch_link_any(a.chunks, 1, (int)targets.size(), a, 0);
+      if (rc) return rc;
+      HTRY(hipGetLastError());
+    }
+    HTRY(hipDeviceSynchronize());
+    at += m;
+    in_graph += (int64_t)m;
+  }
+  // ---- the finished layer 0 back to the host copy (export, files), keys attached ----------------------------------------
+  {
+    std::vector<uint32_t> adj0((size_t)std::max<int64_t>(n, 1) * (ix->m0 + 1));
+    HTRY(hipMemcpy(adj0.data(), ix->adj0.p, adj0.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) {
+      const uint32_t *row = &adj0[(size_t)i * (ix->m0 + 1)];
+      ix->level0[(size_t)i].assign(row + 1, row + 1 + row[0]);
+      ix->has0[(size_t)i] = 1;
+    }
+  }
+  if (ids && n > 0) {
+    HTRY(ix->ids.reserve((size_t)n * 8));
+    HTRY(hipMemcpy(ix->ids.p, ids, (size_t)n * 8, hipMemcpyHostToDevice));
+    ix->has_ids = true;
+  }
   *out = ix.release();
   return HNSW_OK;
 }

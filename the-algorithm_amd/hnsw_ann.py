@@ -25,6 +25,8 @@ PROTOS = {
                                           C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
     "hnsw_index_build_insert_levels": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                                  C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "hnsw_index_build_insert_gpu": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                              C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
     "hnsw_index_graph_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "hnsw_index_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hnsw_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -75,13 +77,17 @@ class Hnsw:
     @classmethod
     def build(cls, metric: DistanceMetric, vectors: np.ndarray, ids: Optional[Sequence[int]] = None, *, max_m: int = 16,
               ef_construction: int = 200, seed: int = 1, n_threads: int = 1, device: int = 0,
-              levels: Optional[Sequence[int]] = None) -> "Hnsw":
+              levels: Optional[Sequence[int]] = None, gpu: bool = False, batch: int = 0) -> "Hnsw":
         """Insert the vectors one by one with the reference's algorithm (HnswIndex.insert), on the host.
         levels: every item's level, instead of the seeded draw (int)(-ln U / ln maxM)."""
         lib = _lib()
         v = np.ascontiguousarray(vectors, np.float32)
         i = None if ids is None else np.ascontiguousarray(ids, np.int64)
         h = C.c_void_p()
+        if gpu:  # batched construction on the device (hnsw_index_build_insert_gpu)
+            _check(lib, lib.hnsw_index_build_insert_gpu(device, int(metric), v.shape[0], v.shape[1], _p(v), _p(i), max_m,
+                                                        ef_construction, seed, batch, C.byref(h)))
+            return cls(h, metric, v.shape[0], v.shape[1], max_m)
         if levels is not None:
             lv = np.ascontiguousarray(levels, np.int32)
             if lv.shape != (v.shape[0],):

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--max-m", type=int, default=16)
     ap.add_argument("--ef-construction", type=int, default=200)
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--build", choices=["host", "gpu"], default="host", help="host: the reference's insertion, 16 threads; gpu: the batched device builder")
     ap.add_argument("--configs", default="10:100,200:800")
     ap.add_argument("--clusters", type=int, default=0, help="synthetic data: 0 = i.i.d. N(0,1) (SURVEY 8d), n = mixture of n Gaussians")
     ap.add_argument("--steps", type=int, default=3)
@@ -38,7 +39,7 @@ def main():
         x = rng.standard_normal((a.vectors, a.dim)).astype(np.float32)
         q = rng.standard_normal((a.queries, a.dim)).astype(np.float32)
     t0 = time.time()
-    ix = pkg.hnsw_ann.Hnsw.build(m, x, max_m=a.max_m, ef_construction=a.ef_construction, seed=1, n_threads=a.threads)
+    ix = pkg.hnsw_ann.Hnsw.build(m, x, max_m=a.max_m, ef_construction=a.ef_construction, seed=1, n_threads=a.threads, gpu=a.build == "gpu")
     build_s = time.time() - t0
     bf = pkg.dense_ann.BruteForceIndex.build(m, x)
     # CPU leg: the reference's walk (HnswIndex.searchKnn, restated in oracle/hnsw_oracle.c) over the SAME graph, one
@@ -84,7 +85,7 @@ def main():
                          "unit": "GB/s", "frac": st["distance_evals"] * row_bytes / (st["kernel_ms"] * 1e-3) / 8e12,
                          "note": "random 512-B row gathers; latency-bound walk"},
             "cpu_baseline": cpu,
-            "spilled_queries": st["spilled_queries"], "build_s": build_s, "build_threads": a.threads}), flush=True)
+            "spilled_queries": st["spilled_queries"], "build_s": build_s, "build": a.build, "build_threads": a.threads}), flush=True)
     ix.close(); bf.close()
 
 
