@@ -16,13 +16,13 @@ from __graft_entry__ import load_package  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--vectors", type=int, default=200_000)
+    ap.add_argument("--vectors", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=256)
     ap.add_argument("--queries", type=int, default=4096)
     ap.add_argument("--max-m", type=int, default=16)
     ap.add_argument("--ef-construction", type=int, default=200)
     ap.add_argument("--threads", type=int, default=16)
-    ap.add_argument("--build", choices=["host", "gpu"], default="host", help="host: the reference's insertion, 16 threads; gpu: the batched device builder")
+    ap.add_argument("--build", choices=["host", "gpu"], default="gpu", help="host: the reference's insertion, 16 threads; gpu: the batched device builder")
     ap.add_argument("--configs", default="10:100,200:800")
     ap.add_argument("--clusters", type=int, default=0, help="synthetic data: 0 = i.i.d. N(0,1) (SURVEY 8d), n = mixture of n Gaussians")
     ap.add_argument("--steps", type=int, default=3)
