@@ -996,8 +996,9 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
 hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int max_n_scan, int k_local_floor, hipStream_t stream) {
   if (n_units <= 0) return hipSuccess;
   const int items_cap = ix.P * (max_n_scan < NSCAN_MAX ? (max_n_scan > 0 ? max_n_scan : 1) : NSCAN_MAX);
-  // (with fewer than 16 partitions a query has too few sub-lists to occupy a workgroup: 40 us against 33 at P = 8)
-  if (ix.P >= 16 && ix.P * NSCAN_MAX <= DESC_Q_ITEMS)
+  // (one workgroup per query from 8 partitions up: the cluster-level cut's sort is then done once per query, not once per
+  // unit -- 38 us against 54 for an 8-GPU shard's 65536 units)
+  if (ix.P >= 8 && ix.P * NSCAN_MAX <= DESC_Q_ITEMS)
     hipLaunchKernelGGL(desc_query_kernel, dim3((unsigned)b.nq), dim3(256), (size_t)items_cap * 8, stream, ix, b, items_cap, k_local_floor);
   else
     hipLaunchKernelGGL(desc_kernel, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, ix, b, n_units, k_local_floor);

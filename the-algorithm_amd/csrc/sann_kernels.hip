@@ -504,19 +504,32 @@ __device__ inline int rank_among_runs(const ulonglong2 *runs, int R, int r, int 
 __device__ bool sample_cut(const uint64_t *hi, const uint64_t *lo, int n, int need, int budget, ulonglong2 *s_tmp, int *s_ctl,
                            uint64_t &thr_hi, uint64_t &thr_lo) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int idx = (int)(((long long)tid * n) / WG);
-  uint64_t sh = hi[idx], sl = lo[idx];
-  wave_sort_desc_k128(sh, sl);
-  s_tmp[tid] = make_ulonglong2(sh, sl);
-  __syncthreads();
-  const int rank = rank_among_runs<WG / 64>(s_tmp, WG / 64, wv, lane, sh, sl);
-  __syncthreads();
-  s_tmp[rank] = make_ulonglong2(sh, sl);  // (ranks are a permutation)
-  __syncthreads();
+  // A window that is wide against n (a shard's merge: need = its cut list length, budget = 256 of ~380 staged) is hit
+  // from 64 samples, which one wave sorts on its own: no rank merge, and the other waves go straight to the sweep.
+  const int NS = (budget - need) * 4 >= n ? 64 : WG;  // (uniform)
+  if (NS == 64) {
+    if (wv == 0) {
+      const int idx = (int)(((long long)lane * n) / 64);
+      uint64_t sh = hi[idx], sl = lo[idx];
+      wave_sort_desc_k128(sh, sl);
+      s_tmp[lane] = make_ulonglong2(sh, sl);
+    }
+    __syncthreads();
+  } else {
+    const int idx = (int)(((long long)tid * n) / WG);
+    uint64_t sh = hi[idx], sl = lo[idx];
+    wave_sort_desc_k128(sh, sl);
+    s_tmp[tid] = make_ulonglong2(sh, sl);
+    __syncthreads();
+    const int rank = rank_among_runs<WG / 64>(s_tmp, WG / 64, wv, lane, sh, sl);
+    __syncthreads();
+    s_tmp[rank] = make_ulonglong2(sh, sl);  // (ranks are a permutation)
+    __syncthreads();
+  }
   const int target = (need + budget) / 2;
-  int j = (int)(((long long)target * WG) / n) - 1;
-  j = j < 0 ? 0 : (j > WG - 1 ? WG - 1 : j);
-  int j_small = -1, j_big = WG;  // samples known to give too few / too many
+  int j = (int)(((long long)target * NS) / n) - 1;
+  j = j < 0 ? 0 : (j > NS - 1 ? NS - 1 : j);
+  int j_small = -1, j_big = NS;  // samples known to give too few / too many
   for (int attempt = 0; attempt < 6; attempt++) {
     const ulonglong2 t = s_tmp[j];
     int c = 0;
@@ -533,7 +546,7 @@ __device__ bool sample_cut(const uint64_t *hi, const uint64_t *lo, int n, int ne
     }
     if (C < need) j_small = j; else j_big = j;
     if (j_big - j_small <= 1) return false;
-    int step = (int)(((long long)(target - C) * WG) / n);
+    int step = (int)(((long long)(target - C) * NS) / n);
     if (step == 0) step = C < need ? 1 : -1;
     j += step;
     j = j <= j_small ? j_small + 1 : (j >= j_big ? j_big - 1 : j);

@@ -13,9 +13,11 @@ lib = pkg.load_library()
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
 ALG = {"cosine": "CosineSimilarity", "logcosine": "LogCosineSimilarity", "dot": "DotProduct"}[sys.argv[3] if len(sys.argv) > 3 else "cosine"]
-offs, cids, scs = pkg.corpus.make_queries(1024)
-index = pkg.ClusterTweetIndex.synthetic(T, n_partitions=P)
-cfg = pkg.SimClustersANNConfig(maxNumResults=400, annAlgorithm=getattr(pkg.ScoringAlgorithm, ALG))
+N = int(sys.argv[4]) if len(sys.argv) > 4 else 1      # shard 0 of N (1024 N queries), as tools/shard_cost.py
+K = int(sys.argv[5]) if len(sys.argv) > 5 else 400    # per-shard list length
+offs, cids, scs = pkg.corpus.make_queries(1024 * N)
+index = pkg.ClusterTweetIndex.synthetic(T, n_partitions=P, shard_id=0, n_shards=N)
+cfg = pkg.SimClustersANNConfig(maxNumResults=K, annAlgorithm=getattr(pkg.ScoringAlgorithm, ALG))
 qb = pkg.QueryBatch(index, offs, cids, scs, cfg, now_ms=pkg.corpus.NOW_MS)
 for _ in range(3):
     qb.run(); qb.finish()
