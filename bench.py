@@ -140,12 +140,11 @@ def main():
     nq = args.queries_per_gpu * world
     nql = args.queries_per_gpu  # queries this rank owns (finalises); it still answers all nq on its shard
     if world > 1:
-        # a shard holds 1/world of every posting list: keep the (query, partition) units about the same
-        # size by partitioning the shard world times less finely -- but not below 8 partitions: a unit
-        # must hand over ~k/P candidates and its survivor list holds 160 (measured with
-        # tools/shard_cost.py: at N = 8, P = 4 sends ~100 units per batch to the general path, 1.04 ms
-        # per GPU-step; P = 8 none, 0.65 ms; P = 16 0.78 ms)
-        p = max(8, (args.partitions or 32) // world)
+        # a shard holds 1/world of every posting list: keep the (query, partition) units about the same size by
+        # partitioning the shard world times less finely, down to 4 partitions (measured with tools/shard_cost.py on the
+        # round-2 kernels, GPU-side step per 1024*N-query batch: N = 2: P = 32 / 16 / 8 -> 0.345 / 0.268 / 0.264 ms;
+        # N = 4: P = 16 / 8 / 4 -> 0.374 / 0.290 / 0.270; N = 8: P = 8 / 4 -> 0.383 / 0.308; no unit falls back in any)
+        p = max(4, (args.partitions or 32) // world)
         args.partitions = 1 << (p.bit_length() - 1)
     offs, cids, scs = pkg.corpus.make_queries(nq)
     now_ms = pkg.corpus.NOW_MS

@@ -231,19 +231,19 @@ def test_edge_cases(pkg, oracle, small):
     ix2.close()
 
 
-def test_tweet_hash_shards_merge_exactly(pkg, oracle, small):
-    """Two tweet-hash shards on one GPU + sann_merge_shards == the unsharded answer (the
-    ComposedQueryable pattern, ShardApi.scala:71-87)."""
+@pytest.mark.parametrize("S,P", [(3, 8), (8, 4)])
+def test_tweet_hash_shards_merge_exactly(pkg, oracle, small, S, P):
+    """S tweet-hash shards on one GPU + sann_merge_shards == the unsharded answer (the
+    ComposedQueryable pattern, ShardApi.scala:71-87); (8, 4) is the partitioning bench.py gives 8 GPUs."""
     import ctypes as C
     import torch
 
     co, offs, cids, scs = small
     cfg = pkg.SimClustersANNConfig(maxNumResults=400, maxTopTweetsPerCluster=300)
     nq = len(offs) - 1
-    S = 3
     batches, bufs = [], []
     for s in range(S):
-        ix = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=8, shard_id=s,
+        ix = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=P, shard_id=s,
                                    n_shards=S)
         qb = pkg.QueryBatch(ix, offs, cids, scs, cfg, now_ms=co.now_ms)
         qb.run(); qb.finish()
