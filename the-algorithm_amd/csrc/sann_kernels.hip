@@ -711,6 +711,10 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
   // barrier-separated stages, 32 k clk; ranking every entry against ALL other runs at once was bound by LDS bandwidth,
   // 24 k clk with four queries per CU.)
   uint64_t xk_hi = 0, xk_lo = 0;
+  // (the sorted entries go to the output at the very END of the kernel: a barrier behind global stores waits for them)
+  constexpr int PER_OUT = SURV / WG < 1 ? 1 : SURV / WG;
+  int o_at[PER_OUT], cnt_out = 0;
+  uint64_t o_hi[PER_OUT], o_lo[PER_OUT];
   {
     int np = next_pow2(best_n);
     np = np < 64 ? 64 : np;
@@ -738,13 +742,34 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
     __syncthreads();
     MSTAMP(5);  // runs sorted
     for (int L = 64; L < np; L <<= 1) {  // (uniform)
+      // the thread's entries search their partner runs in lock step: PER independent chains of LDS reads, not one after
+      // the other (the chains are all this phase waits for)
+      const ulonglong2 *run[PER];
+      int pos[PER];
+      bool second[PER];
 #pragma unroll
       for (int j = 0; j < PER; j++) {
-        if (wv + j * (WG / 64) < R) {
-          const int base = at[j] & ~(2 * L - 1), off = at[j] & (L - 1);
-          const bool second = (at[j] & L) != 0;  // in the pair's second run: equal keys of the first run come before
-          at[j] = base + off + run_count_before_n(s_e2 + base + (second ? 0 : L), L, mh[j], ml[j], second);
+        const int base = at[j] & ~(2 * L - 1);
+        second[j] = (at[j] & L) != 0;  // in the pair's second run: equal keys of the first run come before
+        run[j] = s_e2 + base + (second[j] ? 0 : L);
+        pos[j] = 0;
+      }
+      for (int step = L >> 1; step >= 1; step >>= 1) {
+        ulonglong2 v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) v[j] = run[j][pos[j] + step - 1];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+          const bool before = v[j].x > mh[j] || (v[j].x == mh[j] && (v[j].y > ml[j] || (v[j].y == ml[j] && second[j])));
+          pos[j] += before ? step : 0;
         }
+      }
+#pragma unroll
+      for (int j = 0; j < PER; j++) {
+        const ulonglong2 v = run[j][L - 1];
+        const bool before = v.x > mh[j] || (v.x == mh[j] && (v.y > ml[j] || (v.y == ml[j] && second[j])));
+        const int cntb = pos[j] + ((pos[j] == L - 1 && before) ? 1 : 0);
+        if (wv + j * (WG / 64) < R) at[j] = (at[j] & ~(2 * L - 1)) + (at[j] & (L - 1)) + cntb;
       }
       if (2 * L >= np) break;  // merged completely: at[] is the rank
       __syncthreads();
@@ -753,20 +778,17 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
         if (wv + j * (WG / 64) < R) s_e2[at[j]] = make_ulonglong2(mh[j], ml[j]);
       __syncthreads();
     }
-    const int cnt = best_n < k ? best_n : k;
+    cnt_out = best_n < k ? best_n : k;
 #pragma unroll
     for (int j = 0; j < PER; j++) {
-      if (wv + j * (WG / 64) < R && at[j] < cnt) {
-        out_ids[at[j]] = key_id(ml[j]);
-        out_scores[at[j]] = key_score(mh[j]);
-        if (at[j] == cnt - 1 && cnt == k) { s_mm[0] = mh[j]; s_mm[1] = ml[j]; }  // the k-th key
-      }
+      o_at[j] = (wv + j * (WG / 64) < R && at[j] < cnt_out) ? at[j] : -1;
+      o_hi[j] = mh[j];
+      o_lo[j] = ml[j];
+      if (o_at[j] == cnt_out - 1 && cnt_out == k) { s_mm[0] = mh[j]; s_mm[1] = ml[j]; }  // the k-th key
     }
-    if (tid == 0) ((int32_t *)((char *)b.out_counts + out_shift))[ql] = cnt;
     __syncthreads();
-    if (cnt == k && cnt > 0) { xk_hi = s_mm[0]; xk_lo = s_mm[1]; }
+    if (cnt_out == k && cnt_out > 0) { xk_hi = s_mm[0]; xk_lo = s_mm[1]; }
   }
-  __syncthreads();
   // candidateScoresMap.size (:102) and the exactness proof: every candidate a unit withheld has
   // key < unit_thr; it cannot belong to the top-k iff unit_thr <= the k-th key.  With fewer than
   // k results there is no k-th key, so any withholding unit makes the result unproven.
@@ -795,7 +817,14 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
       b.status[2 + o] = q;  // status[2..] = list of inexact queries
     }
   }
-  MSTAMP(6);  // written + proof
+#pragma unroll
+  for (int j = 0; j < PER_OUT; j++)
+    if (o_at[j] >= 0) {
+      out_ids[o_at[j]] = key_id(o_lo[j]);
+      out_scores[o_at[j]] = key_score(o_hi[j]);
+    }
+  if (tid == 0) ((int32_t *)((char *)b.out_counts + out_shift))[ql] = cnt_out;
+  MSTAMP(6);  // proof + written
 #undef MSTAMP
 }
 
