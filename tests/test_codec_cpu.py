@@ -162,3 +162,40 @@ def test_nearest_neighbor_result(pkg):
     assert ac.encode_neighbor_result(1, [9]) == bare
     gi, gd, ga, _ = ac.decode_neighbor_result(bare)
     assert list(gi) == [9] and list(ga) == [0]
+
+
+def test_random_round_trips(pkg):
+    """Random values through every codec and back: what was encoded is what decodes, byte counts agree."""
+    ac, sa = pkg.ann_codec, pkg.simclusters_ann
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        cfg = sa.SimClustersANNConfig(maxNumResults=int(rng.integers(-5, 2000)), minScore=float(rng.normal()),
+                                      candidateEmbeddingType=int(rng.integers(0, 400)), maxTopTweetsPerCluster=int(rng.integers(0, 5000)),
+                                      maxScanClusters=int(rng.integers(0, 200)), maxTweetCandidateAgeHours=int(rng.integers(0, 200000)),
+                                      minTweetCandidateAgeHours=int(rng.integers(0, 50)), annAlgorithm=sa.ScoringAlgorithm(int(rng.integers(1, 5))))
+        kind = int(rng.choice([1, 2, 3, 5, 4, 10]))
+        if kind in (1, 2, 3):
+            iid = ac.InternalId(kind, int(rng.integers(-(1 << 62), 1 << 62)), I64)
+        elif kind == 5:
+            iid = ac.InternalId(5, int(rng.integers(0, 1 << 30)), I32)
+        else:
+            raw = bytes(rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8))
+            iid = ac.InternalId(kind, 0, STRING, binary(raw))
+        q = ac.Query(int(rng.integers(1, 11000)), int(rng.integers(1, 7)), iid, cfg)
+        seq = int(rng.integers(-(1 << 31), 1 << 31))
+        enc = ac.encode_call(seq, q)
+        assert ac.decode_call(enc) == (seq, q, len(enc))
+        n = int(rng.integers(0, 50))
+        ids = rng.integers(-(1 << 62), 1 << 62, n)
+        sc = rng.normal(size=n)
+        rep = ac.encode_reply(seq, ids, sc)
+        s2, i2, c2, used = ac.decode_reply(rep)
+        assert (s2, used) == (seq, len(rep)) and np.array_equal(i2, ids) and np.array_equal(c2.view(np.int64), sc.view(np.int64))
+        ne = int(rng.integers(0, 30))
+        lv = rng.integers(0, 5, ne).astype(np.int32)
+        keys = rng.integers(-(1 << 62), 1 << 62, ne)
+        lens = rng.integers(0, 33, ne)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        nb = rng.integers(-(1 << 62), 1 << 62, int(off[-1]))
+        g = ac.decode_graph(ac.encode_graph(lv, keys, off, nb))
+        assert np.array_equal(g[0], lv) and np.array_equal(g[1], keys) and np.array_equal(g[2], off) and np.array_equal(g[3], nb)

@@ -13,7 +13,7 @@ def _recall(ix, bf_ids, q, k, ef):
     return float(np.mean([len(set(ids[i, :cnt[i]]) & set(bf_ids[i])) / k for i in range(len(q))]))
 
 
-@pytest.mark.parametrize("metric", ["Cosine", "L2"])
+@pytest.mark.parametrize("metric", ["Cosine", "L2", "InnerProduct"])
 def test_gpu_built_graph_is_well_formed_and_recalls_like_the_host_built_one(pkg, oracle, metric):
     m = getattr(pkg.dense_ann.DistanceMetric, metric)
     rng = np.random.default_rng(5)
