@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "liboracle.so")
+LIB = os.environ.get("ORACLE_LIB_PATH") or os.path.join(_HERE, "liboracle.so")  # (override: a sanitizer build of the same sources)
 
 
 class oracle_sann_config(C.Structure):
