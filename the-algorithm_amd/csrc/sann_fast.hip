@@ -370,6 +370,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   const bool overflow_T = overflow && !overflow_n;
   __syncthreads();
   STAMP(1);  // descriptors + map done
+  ABLATE(6, (unsigned long long)T + s_map[tid] + s_begin[tid & (NS - 1)] + s_pre[tid & (NS - 1)] + s_wkey[tid & (NS - 1)] + (unsigned long long)s_w[tid & (NS - 1)]);
 
   // entries a unit must offer before it may withhold the rest (unit_kl), and the size up to which it simply offers
   // everything
@@ -430,6 +431,12 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
 #pragma unroll
       for (int u0 = 0; u0 < U; u0 += 4)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[u0]), "+v"(raw[u0 + 1]), "+v"(raw[u0 + 2]), "+v"(raw[u0 + 3]) : : "memory");
+    }
+    if constexpr (ABL == 7) {
+      unsigned long long x_ = 0;
+#pragma unroll
+      for (int u = 0; u < U; u++) x_ ^= ((unsigned long long)(raw[u].y ^ raw[u].w) << 32) | (raw[u].x ^ raw[u].z ^ (unsigned)seq[u]);
+      ABLATE(7, x_);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -771,6 +778,14 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
       int base = 0;
       if ((tid & 63) == 0 && total) base = atomicAdd(&s_ctl[CTL_NSURV], total);
       base = __builtin_amdgcn_readfirstlane(base);
+      {
+        unsigned long long x_ = 0;
+        if constexpr (ABL == 8) {
+#pragma unroll
+          for (int u = 0; u < U; u++) x_ ^= (unsigned long long)__float_as_uint(s32[u]) ^ (unsigned)seq[u];
+        }
+        ABLATE(8, x_ + (unsigned)(incl + base + total));
+      }
       if (total != 0 && base + total <= SCAP) {  // uniform per wave; a list that would not fit is an overflow below
         int o = base + incl - cnt;
 #pragma unroll
@@ -783,6 +798,14 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
       }
     }
     __syncthreads();
+    {
+      unsigned long long x_ = 0;
+      if constexpr (ABL == 9) {
+#pragma unroll
+        for (int u = 0; u < U; u++) x_ ^= (unsigned long long)__float_as_uint(s32[u]);
+      }
+      ABLATE(9, x_ + s_ent[tid & 63] + (unsigned)s_ctl[CTL_NSURV]);
+    }
     // the cluster-level cut counted postings the filters then removed: cut by the data after all
     if (!cut_by_data && tau != 0u && s_ctl[CTL_NSURV] < kl && s_ctl[CTL_NSURV] < s_ctl[CTL_LIVE] && !s_ctl[CTL_BAD] && !overflow) {
       __syncthreads();  // (everyone has read the counters)
@@ -1039,6 +1062,10 @@ hipError_t launch_unit_ablation(const IndexView &ix, const BatchView &b, const F
     case 3: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 3>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
     case 4: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 4>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
     case 5: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 5>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 6: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 6>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 7: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 7>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 8: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 8>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
+    case 9: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 9>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

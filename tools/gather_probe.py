@@ -21,7 +21,7 @@ for _ in range(3):
 st = qb.stats()
 print("P", P, "postings", st.postings_scanned, "bytes", st.algorithmic_bytes, "max unit", st.max_unit_postings)
 ms, cs = C.c_double(), C.c_uint64()
-for mode, wgs in [(0, 1), (1, 6), (11, 1), (12, 1), (13, 1), (14, 1), (15, 1), (10, 1)]:
+for mode, wgs in [(0, 1), (1, 6), (16, 1), (17, 1), (11, 1), (12, 1), (13, 1), (14, 1), (18, 1), (19, 1), (15, 1), (10, 1)]:
     rc = lib.sann_debug_gather_probe(qb._h, mode, wgs, 10, C.byref(ms), C.byref(cs))
     assert rc == 0, lib.sann_last_error()
     print(f"mode {mode} wgs/cu {wgs}: {ms.value*1e3:8.1f} us  {st.algorithmic_bytes/ms.value/1e9:7.2f} TB/s  checksum {cs.value:016x}")
