@@ -53,6 +53,14 @@ struct IndexView {
   int32_t log2P;
 };
 
+// A fast unit's candidate list is handed to the merge kernel in one of three forms per entry (cand_key / cand_id):
+//   key >= 2           final: (score_key, tweet id)
+//   key == CAND_DEFERRED   id = cluster sequence number << 32 | posting position: the merge kernel fetches the posting and
+//                          does the exact fp64 arithmetic (ApproximateCosineSimilarity.scala:92-125) itself
+//   key == CAND_DROPPED    nothing (a candidate that failed `score >= minScore`)
+// (score_key never yields 0 or 1 for a score that passed `>= minScore`: they are the images of two negative NaNs.)
+constexpr unsigned long long CAND_DEFERRED = 0ull, CAND_DROPPED = 1ull;
+
 // Unit flags
 enum : uint32_t {
   UNIT_OK = 0,

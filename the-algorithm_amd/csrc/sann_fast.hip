@@ -57,7 +57,7 @@ namespace sann {
 constexpr int NSCAN_MAX = 128;   // scanned clusters a fast unit can describe
 // Per-unit side tables are sized by the unit's posting capacity (WG*U) so that small units keep
 // LDS small and occupancy high:
-//   blocked Bloom filter  capacity/2 64-bit words (>= 256), 3 bits per posting: ~0.02 % false flags
+//   blocked Bloom filter  capacity/2 64-bit words (>= 256), 4 bits per posting (two per 32-bit half): ~0.005 % false flags
 //   "flagged" filter      256 words
 //   match list            64 entries up to 1024 postings, 128 above
 constexpr float APPROX_EPS = 4e-6f;  // bound on |approx/exact - 1| of the fp32 pre-filter (actual < 1e-6)
@@ -247,9 +247,15 @@ __global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, in
 
 // Three bit positions inside the posting's 64-bit Bloom word.  (A fourth -- fewer false flags: one unit in twelve instead
 // of one in five at the benchmark's shape -- was measured and cost more in every unit than it saved in the flagged ones.)
+// FOUR bits of a 64-bit word, two in either half (20 hash bits).  Three bits anywhere in the word flagged one unit in
+// five at the benchmark's shape (1264 postings over 2048 words: 0.19 false flags per unit, and a flagged unit lives 65 %
+// longer); two per half flag one in seventeen, and the halves are built by 32-bit shifts (8 instructions, not 13).
 __device__ inline unsigned long long bloom_bits(uint32_t hv) {
-  return (1ull << (hv & 63)) | (1ull << ((hv >> 6) & 63)) | (1ull << ((hv >> 12) & 63));
+  const uint32_t lo = (1u << (hv & 31)) | (1u << ((hv >> 5) & 31));
+  const uint32_t hi = (1u << ((hv >> 10) & 31)) | (1u << ((hv >> 15) & 31));
+  return ((unsigned long long)hi << 32) | lo;
 }
+constexpr int BLOOM_POS_BITS = 20;
 
 constexpr int bloom_log2(int capacity) { return capacity <= 512 ? 8 : capacity <= 1024 ? 9 : 11; }
 
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   constexpr int SCAP = FAST_SCAP;
   constexpr int BW = bloom_log2(WG * U);  // log2 of the Bloom filter's 64-bit words
   constexpr int BLOOM_ALLOC = 1 << BW;
-  constexpr int HB = 18 + BW;  // hash bits: 3 x 6 bit positions, then the word index
+  constexpr int HB = BLOOM_POS_BITS + BW;  // hash bits: 4 x 5 bit positions, then the word index
   constexpr int FBLOOM_WORDS = BW >= 11 ? 64 : 256;  // (beside the 16 KB Bloom filter: 64, so that eight workgroups fit a CU)
   constexpr int FB = BW >= 11 ? 6 : 8;
   constexpr int MCAP = (WG * U <= 1024) ? 64 : 128;
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
       }
     }
     }
-    // ---- 3a. blocked Bloom filter: three bits of one 64-bit word, one returning LDS atomic per posting.  All of a
+    // ---- 3a. blocked Bloom filter: four bits of one 64-bit word, one returning LDS atomic per posting.  All of a
     // thread's atomics are issued before the first result is looked at (one LDS round trip, not U).
     unsigned long long seen[U];
 #pragma unroll
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
       if ((uint32_t)(u * WG) < Tg && seq[u] >= 0) {
         const uint32_t hv = hsh[u];
         const unsigned long long bits = bloom_bits(hv);
-        seen[u] = ~atomicOr(&s_bloom[hv >> 18], bits) & bits;  // bits of this posting that were NOT set before
+        seen[u] = ~atomicOr(&s_bloom[hv >> BLOOM_POS_BITS], bits) & bits;  // bits of this posting that were NOT set before
       }
     }
 #pragma unroll
@@ -856,40 +862,36 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
 
   STAMP(7);  // survivors compacted
   ABLATE(5, (unsigned long long)ns + theta_key + s_ent[tid % SCAP]);
-  // ---- 6. the survivors' postings again (one parallel trip, mostly to L2), exact fp64 scores, emit ------------------
+  // ---- 6. hand the survivors over ----------------------------------------------------------------------------------
+  // A survivor's exact fp64 score (a second fetch of its posting, a division and a square root: a chain of ~190 dependent
+  // instructions in ONE wave of the workgroup while the other three waited at the barrier -- 15 % of the kernel) is
+  // computed by the merge kernel, where 512 threads share a query's ~1400 survivors.  What leaves here is
+  // (cluster sequence number, posting position); only representatives of multi-cluster tweets, whose sums live in this
+  // workgroup's LDS, are finished here.  Nothing is dropped below theta any more: a candidate under theta can only
+  // reach the top k of a query whose proof fails anyway (theta > k-th key).
   const int64_t obase = (int64_t)unit * b.cap;
   int i_first = tid;
   asm volatile("" : "+v"(i_first));  // (a fresh index: hipcc otherwise keeps tid * 8 from the first lines alive, in scratch)
   for (int i = i_first; i < ns; i += WG) {
     const unsigned long long e = s_ent[i];
     const int c = (int)(e >> 32);
+    unsigned long long key = CAND_DEFERRED;
     long long idv;
-    double dot, nsq;
     if (c & 0x10000) {
       idv = s_Mid[c & 0xffff];
-      dot = s_Mdot[c & 0xffff];
-      nsq = s_Mnsq[c & 0xffff];
+      const double v = normalise_f(h.alg, s_Mdot[c & 0xffff], s_Mnsq[c & 0xffff], h.l2norm, h.lognorm);
+      key = v >= h.min_score ? score_key(v) : CAND_DROPPED;  // :125 (false for NaN)
     } else {
       const uint32_t pos = s_begin[c] + ((uint32_t)e - s_pre[c]);
-      const Posting ps = ix.postings[pos];
-      idv = ps.id;
-      dot = 0.0 + ps.score * s_w[c];  // getOrElse(tweetId, 0.0) + score * sourceClusterScore  (:92-94)
-      nsq = 0.0 + ps.score * ps.score;  // (:95-96)
-      if constexpr (NORMS) nsq = use_norms ? ix.norms[pos] : nsq;  // tweets_ann.sql:50-51
+      idv = (long long)(((unsigned long long)(uint32_t)c << 32) | pos);
     }
-    const double v = normalise_f(h.alg, dot, nsq, h.l2norm, h.lognorm);
-    const unsigned long long key = score_key(v);
-    if (v >= h.min_score && key >= theta_key) {  // :125 (false for NaN)
-      const int o = atomicAdd(&s_ctl[CTL_CNT], 1);
-      b.cand_key[obase + o] = key;
-      b.cand_id[obase + o] = idv;
-    }
+    b.cand_key[obase + i] = key;
+    b.cand_id[obase + i] = idv;
   }
-  __syncthreads();
   if (tid == 0) {
     const int n_live = s_ctl[CTL_LIVE];
     const bool withheld = n_live > ns;  // candidates below the cut were not examined exactly
-    b.cand_cnt[unit] = s_ctl[CTL_CNT];
+    b.cand_cnt[unit] = ns;
     b.unit_unique[unit] = n_live;
     b.unit_flags[unit] = withheld ? UNIT_TRUNCATED : UNIT_OK;
     b.unit_thr[2 * (int64_t)unit] = withheld ? theta_key : 0ull;

@@ -561,7 +561,7 @@ __device__ bool sample_cut(const uint64_t *hi, const uint64_t *lo, int n, int ne
 // benchmark shape; 768 when the index has <= 8 partitions per cluster and k <= 256 (sharded runs: ~500 candidates
 // per query in all) -- 24 KB of LDS instead of 40, six workgroups per CU instead of four.
 template <int SURV, int MERGE_LDS>
-__global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, const int32_t *query_list) {
+__global__ __launch_bounds__(WG, 4) void merge_kernel(IndexView ix, BatchView b, const int32_t *query_list) {
   __shared__ uint64_t s_hi[MERGE_LDS], s_lo[MERGE_LDS];
   __shared__ uint8_t s_umap[MERGE_LDS];  // new entry -> unit (relative to the round's first unit; P <= 256)
   __shared__ ulonglong2 s_e2[SURV];  // survivors, packed {score key, id key}
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const int i = r * WG + tid;
-        kh[r] = 0;
+        kh[r] = CAND_DROPPED;
         kid[r] = 0;
         if (i < n_new && i < MERGE_LDS) {
           const int u = u_begin + s_umap[i];
@@ -660,12 +660,47 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
           kid[r] = id[j];
         }
       }
+      // Entries a fast unit handed over as (cluster, posting position) (sann_device.h, CAND_DEFERRED): the posting and the
+      // cluster's weight are fetched here -- all of a thread's entries in one trip -- and scored exactly as
+      // ApproximateCosineSimilarity.scala:92-96,111-125 does for a tweet met in one cluster.
+      // (four entries at a time: with all seven in flight the kernel needed 176 registers and lost half its occupancy)
+      constexpr int RC = 4;
+#pragma unroll
+      for (int r0 = 0; r0 < R; r0 += RC) {
+        Posting ps[RC];
+        double wq[RC];
+#pragma unroll
+        for (int rr = 0; rr < RC; rr++) {
+          const int r = r0 + rr;
+          ps[rr] = Posting{0, 0.0};
+          wq[rr] = 0.0;
+          if (r < R && kh[r] == CAND_DEFERRED) {
+            ps[rr] = ix.postings[(uint32_t)kid[r]];
+            wq[rr] = b.scan_w[h.scan_begin + (int)((uint64_t)kid[r] >> 32)];
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RC; rr++) {
+          const int r = r0 + rr;
+          if (r < R && kh[r] == CAND_DEFERRED) {
+            const double dot = 0.0 + ps[rr].score * wq[rr];  // getOrElse(tweetId, 0.0) + score * sourceClusterScore  (:92-94)
+            double nsq = 0.0 + ps[rr].score * ps[rr].score;  // (:95-96)
+            if (h.use_norms) nsq = ix.norms[(uint32_t)kid[r]];  // tweets_ann.sql:50-51 (offline forms: one more trip)
+            const double v = normalise(h.alg, dot, nsq, h.l2norm, h.lognorm);
+            kh[r] = v >= h.min_score ? score_key(v) : CAND_DROPPED;  // :125 (false for NaN)
+            kid[r] = ps[rr].id;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const int i = r * WG + tid;
         if (i < n_new && best_n + i < MERGE_LDS) {
-          s_hi[best_n + i] = kh[r];
-          s_lo[best_n + i] = id_key(kid[r]);
+          // (a dropped entry is staged as the all-zero key, below every real one, and never leaves the staging area)
+          const bool real = kh[r] != CAND_DROPPED;
+          s_hi[best_n + i] = real ? kh[r] : 0ull;
+          s_lo[best_n + i] = real ? id_key(kid[r]) : 0ull;
         }
       }
     }
@@ -682,7 +717,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
     {
       int c = 0;
       if (k > 0)
-        for (int i = tid; i < n; i += WG) c += key_ge(s_hi[i], s_lo[i], thi, tlo) ? 1 : 0;
+        for (int i = tid; i < n; i += WG) c += (s_hi[i] != 0ull && key_ge(s_hi[i], s_lo[i], thi, tlo)) ? 1 : 0;
       const int incl = wave_incl_scan_i32(c);
       if ((tid & 63) == 63) s_ctl[tid >> 6] = incl;
       __syncthreads();
@@ -692,7 +727,7 @@ __global__ __launch_bounds__(WG) void merge_kernel(IndexView ix, BatchView b, co
       if (k > 0)
         for (int i = tid; i < n; i += WG) {
           const uint64_t a = s_hi[i], c2 = s_lo[i];
-          if (key_ge(a, c2, thi, tlo)) {
+          if (a != 0ull && key_ge(a, c2, thi, tlo)) {
             if (o < SURV) s_e2[o] = make_ulonglong2(a, c2);
             o++;
           }
