@@ -246,7 +246,7 @@ struct sann_batch {
   std::vector<int32_t> h_scan_row;
   std::vector<double> h_scan_w;
   std::vector<int32_t> h_k;
-  DevBuf hdr, scan_row, scan_w, desc, unit_T, d_k, q_stat;
+  DevBuf hdr, scan_row, scan_w, scan_wq, desc, unit_T, d_k, q_stat;
   DevBuf cand_key, cand_id, cand_cnt, unit_unique, unit_flags, unit_fb, unit_thr, status, overflow_units;
   DevBuf out_ids, out_scores, out_counts, out_map_sizes, prof;
   // caller-bound output buffers (NULL = the batch's own)
@@ -300,6 +300,8 @@ struct sann_batch {
     b.scan_w = scan_w.as<double>();
     b.q_stat = (device_prep && use_fast) ? q_stat.as<uint4>() : nullptr;
     b.desc = desc.as<uint32_t>();
+    b.scan_wq = scan_wq.as<double>();
+    b.desc_stride = desc_row_stride(fast.max_n_scan);
     b.unit_T = unit_T.as<int32_t>();
     b.unit_pre = unit_T.as<uint32_t>() + n_units;  // (second half of the same allocation)
     for (int j = 0; j < 4; j++) { b.cut[j] = cut_ptr[j]; b.cut_M[j] = cut_M[j]; }
@@ -659,7 +661,8 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
   HIP_TRY(b->hdr.reserve(nqz * sizeof(QueryHdr)));
   HIP_TRY(b->scan_row.reserve(scan_cap * 4));
   HIP_TRY(b->scan_w.reserve(scan_cap * 8));
-  HIP_TRY(b->desc.reserve(scan_cap * (size_t)ix->P * 8));
+  HIP_TRY(b->desc.reserve(nu * (size_t)desc_row_stride(max_ub) * 8));
+  HIP_TRY(b->scan_wq.reserve(nqz * (size_t)desc_row_stride(max_ub) * 8));
   HIP_TRY(b->unit_T.reserve(nu * 8));  // unit_T and unit_pre
   HIP_TRY(b->d_k.reserve(nqz * 4));
   HIP_TRY(b->q_stat.reserve(nqz * 16));
@@ -1226,6 +1229,24 @@ int sann_debug_phase_cycles(sann_batch_t *b, int32_t enable, double *avg16) {
   }
   for (int i = 0; i < 16; i++) avg16[i] = n ? avg16[i] / n : 0.0;
   avg16[15] = n;
+  if (getenv("SANN_PHASE_HIST")) {  // the duplicate phase is bimodal: units that resolve duplicates, and the others
+    long long n_slow = 0;
+    double slow = 0.0, fast = 0.0, slow_total = 0.0, fast_total = 0.0, ph_a = 0.0, ph_b = 0.0, ph_c = 0.0;
+    for (int u = 0; u < b->n_units; u++) {
+      const unsigned long long *s = &h[(size_t)u * 16];
+      if (s[0] == 0 || s[8] == 0) continue;
+      const double dphase = (double)(s[4] - s[3]);
+      if (dphase > 1500.0 && s[9] && s[10]) {
+        n_slow++; slow += dphase; slow_total += (double)(s[8] - s[0]);
+        ph_a += (double)(s[9] - s[3]); ph_b += (double)(s[10] - s[9]); ph_c += (double)(s[4] - s[10]);
+      }
+      else { fast += dphase; fast_total += (double)(s[8] - s[0]); }
+    }
+    fprintf(stderr, "dup phase: %lld of %d units above 1500 clk (mean %.0f clk, lifetime %.0f); the others %.0f clk (lifetime %.0f)\n",
+            n_slow, n, n_slow ? slow / n_slow : 0.0, n_slow ? slow_total / n_slow : 0.0, n - n_slow ? fast / (n - n_slow) : 0.0,
+            n - n_slow ? fast_total / (n - n_slow) : 0.0);
+    if (n_slow) fprintf(stderr, "  flagged units: fetch + match list %.0f clk, settle groups %.0f clk, fold %.0f clk\n", ph_a / n_slow, ph_b / n_slow, ph_c / n_slow);
+  }
   // merge kernel stamps (per query) are reported in slots 9..14: phases 1..6
   {
     double m[7] = {0, 0, 0, 0, 0, 0, 0};

@@ -53,6 +53,9 @@ struct IndexView {
   int32_t log2P;
 };
 
+// entries of a unit's descriptor row (BatchView::desc): 64 while every query of the batch scans <= 64 clusters, else 128
+__host__ __device__ constexpr int desc_row_stride(int max_n_scan) { return max_n_scan <= 64 ? 64 : 128; }
+
 // A fast unit's candidate list is handed to the merge kernel in one of three forms per entry (cand_key / cand_id):
 //   key >= 2           final: (score_key, tweet id)
 //   key == CAND_DEFERRED   id = cluster sequence number << 32 | posting position: the merge kernel fetches the posting and
@@ -76,7 +79,13 @@ struct BatchView {
   // rank < M scanned in this shard), z = scanned clusters, w = 0.  Lets the host learn a batch's shape without
   // having prepared it (device-side preparation, sann_prep.hip).
   uint4 *q_stat;
-  uint32_t *desc;           // [total_scan*P*2] (sub-list start, exclusive prefix of the lengths), unit-major
+  // Descriptor rows at a FIXED stride: unit u's row is desc_stride (64 or 128) pairs (sub-list start, exclusive prefix
+  // of the lengths) at desc + 2 * u * desc_stride, padded behind the query's n_scan clusters with (0, unit_T); the
+  // query's cluster weights lie at scan_wq + q * desc_stride, padded with 0.  The unit kernel finds both from its block
+  // index alone -- the row at a compact offset needed the query header first: one more dependent trip to memory.
+  uint32_t *desc;
+  double *scan_wq;
+  int32_t desc_stride;
   int32_t *unit_T;          // [n_units] postings with rank < M the unit scans
   uint32_t *unit_pre;       // [n_units] cosine forms: the cluster-level cut of the unit (fp32 key; 0 = none), from the descriptor kernel
   const uint32_t *cut[4];   // cached cut tables ([n_rows*P], see sann_index::cut_cache) ...

@@ -212,15 +212,18 @@ __global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, in
     if (lane >= off) { incl0 += t0; incl1 += t1; }
   }
   const uint32_t total0 = __shfl(incl0, 63, 64), total1 = __shfl(incl1, 63, 64);
-  // unit-major layout: the (q, p) unit reads n_scan consecutive (start, prefix) pairs
-  uint32_t *d = b.desc + 2 * ((int64_t)scan_begin * ix.P + (int64_t)p * n_scan);
-  if (lane < n_scan) {
-    d[2 * lane] = base[0];
-    d[2 * lane + 1] = incl0 - len[0];
-  }
-  if (lane + 64 < n_scan) {
-    d[2 * (lane + 64)] = base[1];
-    d[2 * (lane + 64) + 1] = total0 + incl1 - len[1];
+  // the unit's row: desc_stride (start, prefix) pairs, padded behind n_scan with (0, T); the query's weights likewise
+  // (written by the query's first unit)
+  {
+    uint2 *d = reinterpret_cast<uint2 *>(b.desc) + (int64_t)unit * b.desc_stride;
+    const uint32_t T = total0 + total1;
+    d[lane] = lane < n_scan ? make_uint2(base[0], incl0 - len[0]) : make_uint2(0u, T);
+    if (b.desc_stride > 64) d[lane + 64] = lane + 64 < n_scan ? make_uint2(base[1], total0 + incl1 - len[1]) : make_uint2(0u, T);
+    if (p == 0) {
+      double *wq = b.scan_wq + (int64_t)q * b.desc_stride;
+      wq[lane] = lane < n_scan ? b.scan_w[scan_begin + lane] : 0.0;
+      if (b.desc_stride > 64) wq[lane + 64] = lane + 64 < n_scan ? b.scan_w[scan_begin + lane + 64] : 0.0;
+    }
   }
   if (lane == 0) b.unit_T[unit] = (int32_t)(total0 + total1);
   // cluster-level cut (n_scan <= 64: lane c = cluster c): clusters by key, descending, with the low 8 bits of the key
@@ -245,8 +248,6 @@ __global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, in
   if (lane == 0) b.unit_pre[unit] = pre;
 }
 
-// Three bit positions inside the posting's 64-bit Bloom word.  (A fourth -- fewer false flags: one unit in twelve instead
-// of one in five at the benchmark's shape -- was measured and cost more in every unit than it saved in the flagged ones.)
 // FOUR bits of a 64-bit word, two in either half (20 hash bits).  Three bits anywhere in the word flagged one unit in
 // five at the benchmark's shape (1264 postings over 2048 words: 0.19 false flags per unit, and a flagged unit lives 65 %
 // longer); two per half flag one in seventeen, and the halves are built by 32-bit shifts (8 instructions, not 13).
@@ -339,34 +340,43 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
 
   const bool overflow_n = h.n_scan > NS;  // uniform
   // ---- 1. descriptors ----------------------------------------------------------------------
-  // The unit's posting count T and its descriptor row are loaded together: nothing below branches on T before
-  // the descriptor loads are issued (a branch on T first cost a second, serial trip to memory).
+  // The unit's posting count T, its descriptor row and the query's cluster weights are found from the block index alone
+  // (rows of NS entries at a fixed stride, padded behind the query's n_scan clusters with (0, T) / weight 0): they are
+  // loaded together with the query header, in ONE trip to memory.  (Until round 2 the row lay at a compact offset that
+  // the header had to supply first: header -> row -> postings were three dependent trips, now two.)  Nothing below
+  // branches on T or on the header before these loads are issued.
   // (Tv stays a per-lane register until after the loop: a scalar copy would make hipcc wait for it right here)
-  uint32_t Tv = overflow_n ? 0u : (uint32_t)b.unit_T[unit];
+  uint32_t Tv = (uint32_t)b.unit_T[unit];  // (0 for a query that scans more than NSCAN_MAX clusters)
   const float inv_l2_32 = (float)(1.0 / h.l2norm);
-  if (!overflow_n) {
-    const uint32_t *d = b.desc + 2 * ((int64_t)h.scan_begin * ix.P + (int64_t)p * h.n_scan);
+  {
+    const uint2 *d = reinterpret_cast<const uint2 *>(b.desc) + (int64_t)unit * NS;
+    const double *wq = b.scan_wq + (int64_t)q * NS;
     // four lanes per cluster: lane part (0..3) fills a quarter of the cluster's stretch of the map
-    for (int t = tid; t < 4 * h.n_scan; t += WG) {
+#pragma unroll
+    for (int t0 = 0; t0 < 4 * NS; t0 += WG) {
+      const int t = t0 + tid;
+      if (4 * NS % WG != 0 && t >= 4 * NS) break;
       const int c = t >> 2, part = t & 3;
-      const uint2 v = *reinterpret_cast<const uint2 *>(d + 2 * c);
-      const bool last = c + 1 >= h.n_scan;
-      uint32_t nxt = last ? 0u : d[2 * (c + 1) + 1];
+      const uint2 v = d[c];
+      const bool last = c + 1 >= NS;
+      uint32_t nxt = last ? 0u : d[c + 1].y;
       if (part == 0) {
-        const double w = b.scan_w[h.scan_begin + c];
+        const double w = wq[c];
         s_begin[c] = v.x;
         s_pre[c] = v.y;
         s_w[c] = w;
         s_w32[c] = (float)w;
         s_wkey[c] = cosine_cluster_key(h.alg, w, inv_l2_32);
       }
-      // every posting of this cluster records its cluster in the flat map (an oversized unit stops at the map's end)
+      // every posting of this cluster records its cluster in the flat map (an oversized unit stops at the map's end;
+      // a padding entry's stretch is empty)
       asm volatile("" : "+v"(nxt));  // keeps the select on Tv below the loads above
       uint32_t next = last ? Tv : nxt;
       next = next < (uint32_t)(WG * U) ? next : (uint32_t)(WG * U);
       for (uint32_t i = v.y + part; i < next; i += 4) s_map[i] = (uint8_t)c;
     }
   }
+  if (overflow_n) Tv = 0u;
   asm volatile("" : "+v"(Tv));
   const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tv);
   bool overflow = overflow_n;
@@ -398,18 +408,17 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   float s32[U];   // posting score, fp32
   int seq[U];     // cluster sequence number; bit 16 = group representative (low bits: match-list entry); < 0 = no candidate here
   int live = 0;
+  uint32_t hsh[U];  // table_hash of the tweet id (Bloom word and bits): lives until the duplicate phase has looked at it
 #pragma unroll
   for (int u = 0; u < U; u++) {
     seq[u] = -1;
     s32[u] = 0.f;
+    hsh[u] = 0u;
   }
   {
     // an overflowed unit gathers nothing: with Tg = 0 every slot below is skipped, and no separate control path
     // has to be merged with the loaded registers (the merge made hipcc wait for the first slot's load at once)
     const uint32_t Tg = overflow ? 0u : T;
-    uint32_t hsh[U];  // table_hash of the tweet id (Bloom word and bits): lives only as long as this block
-#pragma unroll
-    for (int u = 0; u < U; u++) hsh[u] = 0u;
     // The loads are written as inline asm and waited for by hand.  Left to hipcc, the six 16-byte loads of a thread
     // were given OVERLAPPING destination registers (the id half of one under the score half of the next) with an
     // `s_waitcnt vmcnt(0)` + register copy behind every one of them: six serial trips to memory instead of one.
@@ -512,37 +521,40 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   // earlier postings of the same tweet, and a few hash collisions) joins the match list M; one
   // thread per M entry then settles its group by comparing ids inside M only.
   if (!overflow && s_ctl[CTL_NFLAG] != 0) {
-    // a flagged unit (one in five at the benchmark's shape, mostly by Bloom false positives) fetches its postings
-    // again -- from L2 -- rather than every unit carrying 4 more bytes per posting through the whole kernel
-    Posting pagain[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int c = seq[u] >= 0 ? seq[u] : 0;
-      const uint32_t j = (uint32_t)(u * WG + tid);
-      pagain[u] = seq[u] >= 0 ? ix.postings[s_begin[c] + (j - s_pre[c])] : Posting{0, 0.0};
-    }
+    // a flagged unit (one in five at the benchmark's shape: tweets met in two of the scanned clusters) looks its
+    // postings' hashes up in the flagged filter; only the few that match fetch their posting again (from L2) -- every
+    // unit carrying the 16-byte postings through the whole kernel cost more registers than the kernel has.  (Until
+    // round 2 ALL postings of a flagged unit were fetched and hashed again: 40 % of the flagged unit's extra time.)
     int mi[U];
+    Posting pm[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {  // (all of a thread's fetches in one trip)
+      const uint32_t hv = hsh[u];
+      const unsigned long long bits = bloom_bits(hv);
+      const bool hit = seq[u] >= 0 && (s_fbloom[hv >> (HB - FB)] & bits) == bits;
+      mi[u] = hit ? 0 : -1;
+      pm[u] = Posting{0, 0.0};
+      if (hit) {
+        const int c = seq[u];
+        pm[u] = ix.postings[s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c])];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      mi[u] = -1;
-      if (seq[u] >= 0) {
+      if (mi[u] >= 0) {
         const int c = seq[u];
-        const Posting pm = pagain[u];
-        const uint32_t hv = table_hash(pm.id, HB);
-        const unsigned long long bits = bloom_bits(hv);
-        if ((s_fbloom[hv >> (HB - FB)] & bits) == bits) {
-          const int m = atomicAdd(&s_ctl[CTL_NM], 1);
-          mi[u] = m;
-          if (m < MCAP) {
-            s_Mid[m] = pm.id;
-            s_Mseq[m] = c;
-            s_Msc[m] = pm.score;
-            if constexpr (NORMS) s_Mnrm[m] = use_norms ? ix.norms[s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c])] : 0.0;
-          }
+        const int m = atomicAdd(&s_ctl[CTL_NM], 1);
+        mi[u] = m;
+        if (m < MCAP) {
+          s_Mid[m] = pm[u].id;
+          s_Mseq[m] = c;
+          s_Msc[m] = pm[u].score;
+          if constexpr (NORMS) s_Mnrm[m] = use_norms ? ix.norms[s_begin[c] + ((uint32_t)(u * WG + tid) - s_pre[c])] : 0.0;
         }
       }
     }
     __syncthreads();
+    STAMP(9);  // (flagged units only) matches fetched, match list written
     const int nm = s_ctl[CTL_NM];
     if (nm > MCAP) {
       overflow = true;
@@ -590,6 +602,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
         }
       }
       __syncthreads();
+      STAMP(10);  // groups settled
       int folded = 0;
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -905,6 +918,7 @@ template <int WG, int U>
 static hipError_t launch_one(const IndexView &ix, const BatchView &b, const FastParams &fp, hipStream_t stream) {
   const int nq8 = (b.nq + 7) / 8 * 8;
   const int n_blocks = nq8 * ix.P;
+  if (b.desc_stride != desc_row_stride(fp.max_n_scan)) return hipErrorInvalidValue;  // (the kernel's NS is the row stride)
   if (fp.use_norms) {
     if (fp.max_n_scan <= 64)
       hipLaunchKernelGGL((unit_fast_kernel<WG, U, 64, 0, true>), dim3(n_blocks), dim3(WG), 0, stream, ix, b, fp.k_local, n_blocks);
@@ -1000,6 +1014,7 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
   } else {
     for (int p = tid; p < P; p += 256) b.unit_pre[(int64_t)q * P + p] = 0u;
   }
+  __shared__ uint32_t s_T[DESC_Q_ITEMS / NSCAN_MAX];  // (P <= 32 here)
   for (int p = tid; p < P; p += 256) {  // exclusive prefix over the clusters, per partition
     uint32_t run = 0;
     for (int c = 0; c < n_scan; c++) {
@@ -1008,14 +1023,17 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
       run += l;
     }
     b.unit_T[(int64_t)q * P + p] = (int32_t)run;
+    s_T[p] = run;
   }
   __syncthreads();
-  // unit-major layout: the (q, p) unit reads n_scan consecutive (start, prefix) pairs
-  uint2 *d = reinterpret_cast<uint2 *>(b.desc + 2 * (int64_t)scan_begin * P);
-  for (int o = tid; o < n_items; o += 256) {
-    const int p = o / n_scan, c = o - p * n_scan;
-    d[o] = make_uint2(s_base[c * P + p], s_len[c * P + p]);
+  // unit-major rows of desc_stride (start, prefix) pairs, padded behind n_scan with (0, T); the query's weights likewise
+  const int stride = b.desc_stride, log2s = stride == 64 ? 6 : 7;
+  uint2 *d = reinterpret_cast<uint2 *>(b.desc) + (int64_t)q * P * stride;
+  for (int o = tid; o < P * stride; o += 256) {
+    const int p = o >> log2s, c = o & (stride - 1);
+    d[o] = c < n_scan ? make_uint2(s_base[c * P + p], s_len[c * P + p]) : make_uint2(0u, s_T[p]);
   }
+  for (int c = tid; c < stride; c += 256) b.scan_wq[(int64_t)q * stride + c] = c < n_scan ? b.scan_w[scan_begin + c] : 0.0;
 }
 
 hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int max_n_scan, int k_local_floor, hipStream_t stream) {
@@ -1056,7 +1074,7 @@ hipError_t launch_debug_wave_sort(int n_waves, uint32_t *v, hipStream_t stream) 
 hipError_t launch_unit_ablation(const IndexView &ix, const BatchView &b, const FastParams &fp, int abl, hipStream_t stream) {
   const int nq8 = (b.nq + 7) / 8 * 8;
   const int n_blocks = nq8 * ix.P;
-  if (fp.unit_capacity != 1536) return hipErrorInvalidValue;
+  if (fp.unit_capacity != 1536 || b.desc_stride != 64) return hipErrorInvalidValue;
   switch (abl) {
     case 0: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 0>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;
     case 1: hipLaunchKernelGGL((unit_fast_kernel<256, 6, 64, 1>), dim3(n_blocks), dim3(256), 0, stream, ix, b, fp.k_local, n_blocks); break;

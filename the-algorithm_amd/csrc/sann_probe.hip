@@ -19,7 +19,7 @@ constexpr int NSCAN_MAX_P = 128;
 template <int WG, int U>
 __device__ inline void build_map(const IndexView &ix, const BatchView &b, int q, int p, const QueryHdr &h, uint32_t *s_begin,
                                  uint32_t *s_pre, uint8_t *s_map, uint32_t T) {
-  const uint32_t *d = b.desc + 2 * ((int64_t)h.scan_begin * ix.P + (int64_t)p * h.n_scan);
+  const uint32_t *d = b.desc + 2 * ((int64_t)q * ix.P + p) * b.desc_stride;  // (fixed-stride rows; the first n_scan entries are real)
   for (int t = threadIdx.x; t < 4 * h.n_scan; t += WG) {
     const int c = t >> 2, part = t & 3;
     const uint2 v = *reinterpret_cast<const uint2 *>(d + 2 * c);
