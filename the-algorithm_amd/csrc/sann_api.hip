@@ -163,6 +163,8 @@ int prepare_query_host(const sann_index *ix, int variant, int64_t now_ms, const 
     h.earliest = std::numeric_limits<int64_t>::min();
     h.latest = std::numeric_limits<int64_t>::max();
   }
+  h.inv_l2_32 = (float)(1.0 / h.l2norm);
+  h.inv_ln_32 = (float)(1.0 / h.lognorm);
   // source-tweet exclusion (:90 ; Optimized :56,:67 ; Experimental :59,:70)
   if (variant == SANN_VARIANT_ORIGINAL || variant == SANN_VARIANT_LEGACY) {
     h.excl_enabled = has_src ? 1 : 0;

@@ -40,8 +40,13 @@ struct QueryHdr {
   // offline job (scio/bq_generation/sql/tweets_ann.sql:10-15,50-51): the candidate's normaliser is its tweet's FULL
   // embedding norm -- the per-posting norms column of the index -- instead of the sum of squares over scanned clusters
   int32_t use_norms;
+  // (float)(1 / l2norm), (float)(1 / lognorm): what the unit kernel's fp32 pre-filter multiplies by -- worked out once per
+  // query by the preparation instead of by every wave of every unit (an fp64 division: a dozen instructions)
+  float inv_l2_32;
+  float inv_ln_32;
   int32_t reserved;
 };
+static_assert(sizeof(QueryHdr) == 88, "QueryHdr layout");
 
 struct IndexView {
   const Posting *postings;

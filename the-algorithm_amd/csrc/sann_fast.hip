@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void desc_kernel(IndexView ix, BatchView b, in
   const QueryHdr h = b.hdr[q];
   uint32_t pre = 0u;
   if (query_has_cluster_cut(h)) {  // (uniform)
-    const float inv_l2_32 = (float)(1.0 / h.l2norm);
+    const float inv_l2_32 = h.inv_l2_32;
     const uint32_t kc = lane < n_scan ? cosine_cluster_key(h.alg, b.scan_w[scan_begin + lane], inv_l2_32) : 0u;
     const uint32_t pk = wave_sort_desc_u32(kc ? ((kc & ~0xffu) | (uint32_t)lane) : 0u);
     const int c = (int)(pk & 0xffu);
@@ -265,6 +265,19 @@ enum {
   CTL_N
 };
 
+// Kernel arguments that only the last lines of the unit kernel need, read from the kernarg segment WHEN they are needed.
+// hipcc loads every argument in the first lines of a kernel; with the 80 SGPRs that eight waves per SIMD leave a wave
+// (MI355X_MICROARCH.md: 16 more are the trap handler's), the pointers of the output arrays then sat in spilled SGPRs --
+// v_writelane / v_readlane pairs, a tenth of the kernel's vector instructions -- for the whole kernel.  A volatile load is
+// not hoisted.  (Arguments: IndexView at 0, BatchView behind it.)
+typedef const __attribute__((address_space(4))) char *kernarg_ptr;
+constexpr size_t KERNARG_BATCH = (sizeof(IndexView) + alignof(BatchView) - 1) / alignof(BatchView) * alignof(BatchView);
+template <class T> __device__ inline T late_kernarg(size_t off) {
+  kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  return *(const volatile __attribute__((address_space(4))) T *)(ka + off);
+}
+#define LATE_ARG(field) late_kernarg<decltype(BatchView::field)>(KERNARG_BATCH + offsetof(BatchView, field))
+
 // second launch bound = waves per SIMD: small units are asked to fit 8 waves (<= 64 VGPRs); the
 // rare duplicate-resolution code may spill, the common path does not
 // ABL != 0: measurement builds that stop after a phase (sann_debug_gather_probe modes 11..15; results are garbage)
@@ -280,6 +293,18 @@ enum {
 // NORMS = the batch holds queries of the offline job's forms (QueryHdr.use_norms): a candidate's normaliser is the
 // norms column of the index, carried as a seventh fp32 per posting -- a separate instantiation, so that the online
 // kernel's 64 registers are not touched.
+// a unit the fast path cannot hold: listed for the general path (one thread); reason -> unit_thr[2u + 1], for diagnostics
+__device__ inline void unit_overflowed(int unit, unsigned long long reason) {
+  LATE_ARG(cand_cnt)[unit] = 0;
+  LATE_ARG(unit_unique)[unit] = 0;
+  LATE_ARG(unit_flags)[unit] = UNIT_OVERFLOW;
+  uint64_t *const thr = LATE_ARG(unit_thr);
+  thr[2 * (int64_t)unit] = 0;
+  thr[2 * (int64_t)unit + 1] = reason;
+  const int o = atomicAdd(&LATE_ARG(status)[0], 1);
+  LATE_ARG(overflow_units)[o] = unit;
+}
+
 template <int WG, int U, int NS = NSCAN_MAX, int ABL = 0, bool NORMS = false>
 __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <= 6 ? 8 : U <= 8 ? 5 : U <= 12 ? 3 : 2)) void unit_fast_kernel(IndexView ix, BatchView b, int k_local_floor, int n_blocks_q8) {
   constexpr int SCAP = FAST_SCAP;
@@ -347,7 +372,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   // branches on T or on the header before these loads are issued.
   // (Tv stays a per-lane register until after the loop: a scalar copy would make hipcc wait for it right here)
   uint32_t Tv = (uint32_t)b.unit_T[unit];  // (0 for a query that scans more than NSCAN_MAX clusters)
-  const float inv_l2_32 = (float)(1.0 / h.l2norm);
+  const float inv_l2_32 = h.inv_l2_32;
   {
     const uint2 *d = reinterpret_cast<const uint2 *>(b.desc) + (int64_t)unit * NS;
     const double *wq = b.scan_wq + (int64_t)q * NS;
@@ -671,7 +696,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
         k32[u] = lv ? (__float_as_uint(a) | 0x80000000u) : 0u;
       }
     } else {
-      const float invln = (float)(1.0 / h.lognorm);
+      const float invln = h.inv_ln_32;
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const bool lv = seq[u] >= 0;
@@ -693,7 +718,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
       }
     }
     if (!overflow && s_ctl[CTL_NFLAG] != 0) {  // uniform: only units that resolved duplicates can hold representatives
-      const float invl2 = (float)(1.0 / h.l2norm), invln = (float)(1.0 / h.lognorm);
+      const float invl2 = h.inv_l2_32, invln = h.inv_ln_32;
 #pragma unroll
       for (int u = 0; u < U; u++) {
         if (seq[u] >= 0 && (seq[u] & 0x10000)) {
@@ -836,30 +861,14 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   }
   if (s_ctl[CTL_BAD] && !overflow) overflow = true;
   if (overflow) {
-    if (tid == 0) {
-      b.cand_cnt[unit] = 0;
-      b.unit_unique[unit] = 0;
-      b.unit_flags[unit] = UNIT_OVERFLOW;
-      b.unit_thr[2 * (int64_t)unit] = 0;
-      b.unit_thr[2 * (int64_t)unit + 1] = overflow_n ? 1ull : overflow_T ? 2ull : (s_ctl[CTL_BAD] & 8) ? 3ull : 4ull;
-      const int o = atomicAdd(&b.status[0], 1);
-      b.overflow_units[o] = unit;
-    }
+    if (tid == 0) unit_overflowed(unit, overflow_n ? 1ull : overflow_T ? 2ull : (s_ctl[CTL_BAD] & 8) ? 3ull : 4ull);
     return;
   }
   // A cut that keeps more than the survivor list holds (many candidates sharing threads with larger ones, or a tie
   // group of more than ~100 identical keys -- which no finer cut could split either) sends the unit to the general
   // path.  (Round 1 re-cut such units with a radix histogram over all keys; it fired too rarely to earn its registers.)
   if (s_ctl[CTL_NSURV] > SCAP) {
-    if (tid == 0) {
-      b.cand_cnt[unit] = 0;
-      b.unit_unique[unit] = 0;
-      b.unit_flags[unit] = UNIT_OVERFLOW;
-      b.unit_thr[2 * (int64_t)unit] = 0;
-      b.unit_thr[2 * (int64_t)unit + 1] = 5ull;
-      const int o = atomicAdd(&b.status[0], 1);
-      b.overflow_units[o] = unit;
-    }
+    if (tid == 0) unit_overflowed(unit, 5ull);
     return;
   }
   const int ns = s_ctl[CTL_NSURV] < SCAP ? s_ctl[CTL_NSURV] : SCAP;
@@ -882,7 +891,9 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   // (cluster sequence number, posting position); only representatives of multi-cluster tweets, whose sums live in this
   // workgroup's LDS, are finished here.  Nothing is dropped below theta any more: a candidate under theta can only
   // reach the top k of a query whose proof fails anyway (theta > k-th key).
-  const int64_t obase = (int64_t)unit * b.cap;
+  const int64_t obase = (int64_t)unit * LATE_ARG(cap);
+  uint64_t *const cand_key = LATE_ARG(cand_key);
+  int64_t *const cand_id = LATE_ARG(cand_id);
   int i_first = tid;
   asm volatile("" : "+v"(i_first));  // (a fresh index: hipcc otherwise keeps tid * 8 from the first lines alive, in scratch)
   for (int i = i_first; i < ns; i += WG) {
@@ -892,23 +903,27 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
     long long idv;
     if (c & 0x10000) {
       idv = s_Mid[c & 0xffff];
-      const double v = normalise_f(h.alg, s_Mdot[c & 0xffff], s_Mnsq[c & 0xffff], h.l2norm, h.lognorm);
-      key = v >= h.min_score ? score_key(v) : CAND_DROPPED;  // :125 (false for NaN)
+      // (the query's norms and minScore are read here, by the few lanes that need them, not kept in six SGPRs all along)
+      const QueryHdr *hq = LATE_ARG(hdr) + q;
+      const double l2 = *(const volatile double *)&hq->l2norm, ln = *(const volatile double *)&hq->lognorm;
+      const double v = normalise_f(h.alg, s_Mdot[c & 0xffff], s_Mnsq[c & 0xffff], l2, ln);
+      key = v >= *(const volatile double *)&hq->min_score ? score_key(v) : CAND_DROPPED;  // :125 (false for NaN)
     } else {
       const uint32_t pos = s_begin[c] + ((uint32_t)e - s_pre[c]);
       idv = (long long)(((unsigned long long)(uint32_t)c << 32) | pos);
     }
-    b.cand_key[obase + i] = key;
-    b.cand_id[obase + i] = idv;
+    cand_key[obase + i] = key;
+    cand_id[obase + i] = idv;
   }
   if (tid == 0) {
     const int n_live = s_ctl[CTL_LIVE];
     const bool withheld = n_live > ns;  // candidates below the cut were not examined exactly
-    b.cand_cnt[unit] = ns;
-    b.unit_unique[unit] = n_live;
-    b.unit_flags[unit] = withheld ? UNIT_TRUNCATED : UNIT_OK;
-    b.unit_thr[2 * (int64_t)unit] = withheld ? theta_key : 0ull;
-    b.unit_thr[2 * (int64_t)unit + 1] = 0;
+    LATE_ARG(cand_cnt)[unit] = ns;
+    LATE_ARG(unit_unique)[unit] = n_live;
+    LATE_ARG(unit_flags)[unit] = withheld ? UNIT_TRUNCATED : UNIT_OK;
+    uint64_t *const thr = LATE_ARG(unit_thr);
+    thr[2 * (int64_t)unit] = withheld ? theta_key : 0ull;
+    thr[2 * (int64_t)unit + 1] = 0;
   }
   STAMP(8);  // emitted
 #undef STAMP
@@ -966,7 +981,7 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
   const QueryHdr h = b.hdr[q];
   const bool cluster_cut = query_has_cluster_cut(h);  // (uniform)
   if (cluster_cut && tid < 64) {
-    const float inv_l2_32 = (float)(1.0 / h.l2norm);
+    const float inv_l2_32 = h.inv_l2_32;
     const uint32_t kc = tid < n_scan ? cosine_cluster_key(h.alg, b.scan_w[scan_begin + tid], inv_l2_32) : 0u;
     const uint32_t pk = wave_sort_desc_u32(kc ? ((kc & ~0xffu) | (uint32_t)tid) : 0u);
     const int c = (int)(pk & 0xffu);

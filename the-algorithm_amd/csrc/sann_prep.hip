@@ -229,6 +229,8 @@ __global__ __launch_bounds__(PWG) void prep_kernel(PrepView in) {
       h.earliest = (int64_t)0x8000000000000000ull;
       h.latest = 0x7fffffffffffffffll;
     }
+    h.inv_l2_32 = (float)(1.0 / h.l2norm);
+    h.inv_ln_32 = (float)(1.0 / h.lognorm);
     const bool has_src = in.has_source_tweet && in.has_source_tweet[q] && in.source_tweet_ids;
     if (in.variant == SANN_VARIANT_ORIGINAL || legacy) {
       h.excl_enabled = has_src ? 1 : 0;
