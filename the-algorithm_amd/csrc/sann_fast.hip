@@ -261,7 +261,7 @@ constexpr int BLOOM_POS_BITS = 20;
 constexpr int bloom_log2(int capacity) { return capacity <= 512 ? 8 : capacity <= 1024 ? 9 : 11; }
 
 enum {
-  CTL_NFLAG = 0, CTL_NM, CTL_LIVE, CTL_NSURV, CTL_CNT, CTL_SEL_D, CTL_SEL_A, CTL_SEL_B, CTL_BAD, CTL_KMIN, CTL_KMAX, CTL_PRE,
+  CTL_NFLAG = 0, CTL_NM, CTL_LIVE, CTL_NSURV, CTL_FOLD, CTL_SEL_D, CTL_SEL_A, CTL_SEL_B, CTL_BAD, CTL_KMIN, CTL_KMAX, CTL_PRE,
   CTL_N
 };
 
@@ -636,7 +636,10 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
         seq[u] = role == 1 ? (0x10000 | mi[u]) : (role == 2 ? -1 : seq[u]);
         folded += __popcll(__ballot(role == 2));
       }
-      if ((tid & 63) == 0 && folded) atomicSub(&s_ctl[CTL_LIVE], folded);
+      if ((tid & 63) == 0 && folded) {
+        atomicSub(&s_ctl[CTL_LIVE], folded);
+        atomicAdd(&s_ctl[CTL_FOLD], folded);
+      }
       __syncthreads();
     }
   }
@@ -850,8 +853,11 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
       }
       ABLATE(9, x_ + s_ent[tid & 63] + (unsigned)s_ctl[CTL_NSURV]);
     }
-    // the cluster-level cut counted postings the filters then removed: cut by the data after all
-    if (!cut_by_data && tau != 0u && s_ctl[CTL_NSURV] < kl && s_ctl[CTL_NSURV] < s_ctl[CTL_LIVE] && !s_ctl[CTL_BAD] && !overflow) {
+    // the cluster-level cut counted postings the filters then removed: cut by the data after all.  (With nothing
+    // removed -- live + folded = T -- the count behind the cut is exact; it may then be below kl on purpose: the
+    // descriptor kernel's query-level rule.)
+    if (!cut_by_data && tau != 0u && s_ctl[CTL_NSURV] < kl && s_ctl[CTL_NSURV] < s_ctl[CTL_LIVE] &&
+        s_ctl[CTL_LIVE] + s_ctl[CTL_FOLD] < (int)T && !s_ctl[CTL_BAD] && !overflow) {
       __syncthreads();  // (everyone has read the counters)
       if (tid == 0) s_ctl[CTL_NSURV] = 0;
       cut_by_data = true;
@@ -1010,8 +1016,27 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
     s_len[i] = len;
   }
   __syncthreads();
+  // The query-level rule: clusters in key order until k plus a margin postings are covered in ALL the query's partitions
+  // together.  A cluster's single-cluster candidates share one key, so a cut below that cluster keeps every candidate
+  // that can reach the top k whichever partitions they fell into -- no per-unit allowance for the spread (unit_kl: the
+  // share plus five sigma) is needed, and a query hands ~800 candidates to its merge instead of ~1500.  A unit takes the
+  // stricter of the two cuts.  (Postings that filters or duplicates then remove are what the margin, the unit kernel's
+  // data-dependent re-cut and, in the end, the merge's proof are for.)
+  __shared__ uint32_t s_qpre;
+  if (cluster_cut && tid < 64) {
+    int tot = 0;
+    const uint32_t kc = s_okey[tid];
+    if (kc != 0u)
+      for (int p = 0; p < P; p++) tot += (int)s_len[(int)s_ocl[tid] * P + p];
+    const int cum = wave_incl_scan_i32(tot);
+    const int target = h.k + (h.k / 4 > 64 ? h.k / 4 : 64);
+    const unsigned long long ok = __ballot(kc != 0u && cum >= target);
+    if (tid == 0) s_qpre = ok != 0ull ? cluster_cut_from_key(s_okey[__ffsll((long long)ok) - 1]) : 0u;
+  }
+  if (cluster_cut) __syncthreads();  // (uniform)
   if (cluster_cut) {
     const int kl = unit_kl(h.k, P, k_local_floor);
+    const uint32_t qpre = s_qpre;
     for (int p = tid; p < P; p += 256) {  // clusters in key order until kl postings are covered
       uint32_t pre = 0u;
       int cum = 0;
@@ -1024,7 +1049,7 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
           break;
         }
       }
-      b.unit_pre[(int64_t)q * P + p] = pre;
+      b.unit_pre[(int64_t)q * P + p] = pre > qpre ? pre : qpre;
     }
   } else {
     for (int p = tid; p < P; p += 256) b.unit_pre[(int64_t)q * P + p] = 0u;
