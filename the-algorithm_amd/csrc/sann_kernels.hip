@@ -506,7 +506,7 @@ __device__ bool sample_cut(const uint64_t *hi, const uint64_t *lo, int n, int ne
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // A window that is wide against n (a shard's merge: need = its cut list length, budget = 256 of ~380 staged) is hit
   // from 64 samples, which one wave sorts on its own: no rank merge, and the other waves go straight to the sweep.
-  const int NS = (budget - need) * 4 >= n ? 64 : WG;  // (uniform)
+  const int NS = (budget - need) * 8 >= n ? 64 : WG;  // (uniform; a 112-entry window in ~800 staged: 1/7 of the range, 9 samples wide)
   if (NS == 64) {
     if (wv == 0) {
       const int idx = (int)(((long long)lane * n) / 64);
