@@ -250,7 +250,7 @@ struct sann_batch {
   std::vector<int32_t> h_k;
   DevBuf hdr, scan_row, scan_w, scan_wq, desc, unit_T, d_k, q_stat;
   DevBuf cand_key, cand_id, cand_cnt, unit_unique, unit_flags, unit_fb, unit_thr, status, overflow_units;
-  DevBuf out_ids, out_scores, out_counts, out_map_sizes, prof;
+  DevBuf out_ids, out_scores, out_counts, out_map_sizes, prof, merge_done;
   // caller-bound output buffers (NULL = the batch's own)
   void *bound_ids = nullptr, *bound_scores = nullptr, *bound_counts = nullptr, *bound_map_sizes = nullptr;
   int32_t bound_chunk_q = 0;  // 0 = outputs are one chunk
@@ -329,6 +329,7 @@ struct sann_batch {
     b.out_chunk_q = bound_chunk_q > 0 ? bound_chunk_q : (nq > 0 ? nq : 1);
     b.out_chunk_pitch = bound_chunk_q > 0 ? bound_chunk_pitch : 0;
     b.prof = prof.as<unsigned long long>();
+    b.merge_done = merge_done.as<int32_t>();
     return b;
   }
 };
@@ -681,6 +682,7 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
   HIP_TRY(b->out_scores.reserve(nqz * (size_t)b->stride * 8));
   HIP_TRY(b->out_counts.reserve(nqz * 4));
   HIP_TRY(b->out_map_sizes.reserve(nqz * 4));
+  HIP_TRY(b->merge_done.reserve(nqz * 4));
   HIP_TRY(b->h_qstat.reserve(nqz * 16));
   if (!b->h_status) HIP_TRY(hipHostMalloc((void **)&b->h_status, 2 * 4, hipHostMallocDefault));
   b->h_status[0] = b->h_status[1] = 0;

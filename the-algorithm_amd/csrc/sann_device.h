@@ -125,6 +125,8 @@ struct BatchView {
   int64_t out_chunk_pitch;
   // debug only: per-unit s_memtime stamps at phase boundaries ([n_units*16]); NULL in normal runs
   unsigned long long *prof;
+  // [nq] scratch of the merge launch: 1 = merge_wave_kernel finished the query, the workgroup-per-query kernel skips it
+  int32_t *merge_done;
 };
 
 // Workspace of the general (global-memory table) path, one region per listed unit.

@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
     if (kc != 0u)
       for (int p = 0; p < P; p++) tot += (int)s_len[(int)s_ocl[tid] * P + p];
     const int cum = wave_incl_scan_i32(tot);
-    const int target = h.k + (h.k / 4 > 64 ? h.k / 4 : 64);
+    const int target = h.k + (h.k / 4 > 32 ? h.k / 4 : 32);
     const unsigned long long ok = __ballot(kc != 0u && cum >= target);
     if (tid == 0) s_qpre = ok != 0ull ? cluster_cut_from_key(s_okey[__ffsll((long long)ok) - 1]) : 0u;
   }
@@ -1081,7 +1081,7 @@ hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int
   const int items_cap = ix.P * (max_n_scan < NSCAN_MAX ? (max_n_scan > 0 ? max_n_scan : 1) : NSCAN_MAX);
   // (one workgroup per query from 8 partitions up: the cluster-level cut's sort is then done once per query, not once per
   // unit -- 38 us against 54 for an 8-GPU shard's 65536 units)
-  if (ix.P >= 8 && ix.P * NSCAN_MAX <= DESC_Q_ITEMS)
+  if (ix.P >= 4 && ix.P * NSCAN_MAX <= DESC_Q_ITEMS)
     hipLaunchKernelGGL(desc_query_kernel, dim3((unsigned)b.nq), dim3(256), (size_t)items_cap * 8, stream, ix, b, items_cap, k_local_floor);
   else
     hipLaunchKernelGGL(desc_kernel, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, ix, b, n_units, k_local_floor);

@@ -561,7 +561,7 @@ __device__ bool sample_cut(const uint64_t *hi, const uint64_t *lo, int n, int ne
 // benchmark shape; 768 when the index has <= 8 partitions per cluster and k <= 256 (sharded runs: ~500 candidates
 // per query in all) -- 24 KB of LDS instead of 40, six workgroups per CU instead of four.
 template <int SURV, int MERGE_LDS>
-__global__ __launch_bounds__(WG, 4) void merge_kernel(IndexView ix, BatchView b, const int32_t *query_list) {
+__global__ __launch_bounds__(WG, 4) void merge_kernel(IndexView ix, BatchView b, const int32_t *query_list, const int32_t *skip_done) {
   __shared__ uint64_t s_hi[MERGE_LDS], s_lo[MERGE_LDS];
   __shared__ uint8_t s_umap[MERGE_LDS];  // new entry -> unit (relative to the round's first unit; P <= 256)
   __shared__ ulonglong2 s_e2[SURV];  // survivors, packed {score key, id key}
@@ -573,6 +573,7 @@ __global__ __launch_bounds__(WG, 4) void merge_kernel(IndexView ix, BatchView b,
 
   const int tid = threadIdx.x;
   const int q = query_list ? query_list[blockIdx.x] : blockIdx.x;
+  if (skip_done && skip_done[q]) return;  // (uniform) merge_wave_kernel has finished this query
   const QueryHdr h = b.hdr[q];
   const int P = ix.P;  // <= 256
   const int64_t unit0 = (int64_t)q * P;
@@ -863,6 +864,157 @@ __global__ __launch_bounds__(WG, 4) void merge_kernel(IndexView ix, BatchView b,
 #undef MSTAMP
 }
 
+// The same merge for SMALL queries, one WAVE per query: a shard of an N-GPU run answers N times as many queries, each from
+// a few units (P <= 8) with a couple of hundred candidates in all -- too little for 256 threads and nine barriers (the
+// workgroup kernel took 131 us for an 8-GPU shard's 8192 queries, 40 us for the unsharded batch's 1024).  Here the
+// candidates live in registers (E per lane), every 64 of them are sorted in registers, the runs meet in the wave's own
+// 1 KB x E of LDS and every entry finds its final position by one lock-step search of the other runs: no barrier at
+// all, four queries per workgroup, 32 per CU.  A query that does not fit (more than 64 E candidates, or k above that) is
+// left to merge_kernel: done[q] says which.  Results, proof and statistics are merge_kernel's, entry for entry.
+template <int E, int PMAX>
+__global__ __launch_bounds__(WG, (E <= 4 ? 6 : 4)) void merge_wave_kernel(IndexView ix, BatchView b, int32_t *done) {
+  __shared__ ulonglong2 s_run[WG / 64][E * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int q = blockIdx.x * (WG / 64) + wv;
+  if (q >= b.nq) return;  // (whole waves; nothing below synchronises across waves)
+  const QueryHdr h = b.hdr[q];
+  const int P = ix.P;  // <= PMAX
+  const int64_t unit0 = (int64_t)q * P;
+  const int k = h.k;
+  // per unit (lane u < P): list length, list location, and what the proof and the statistics read
+  int cnt = 0, fb = -1, pf_unique = 0;
+  uint32_t pf_T = 0, pf_flags = 0;
+  uint64_t pf_thi = 0, pf_tlo = 0;
+  if (lane < P) {
+    const int64_t unit = unit0 + lane;
+    cnt = b.cand_cnt[unit];
+    fb = b.unit_fb[unit];
+    pf_unique = b.unit_unique[unit];
+    pf_T = b.q_stat ? (uint32_t)b.unit_T[unit] : 0u;
+    pf_flags = b.unit_flags[unit];
+    pf_thi = b.unit_thr[2 * unit];
+    pf_tlo = b.unit_thr[2 * unit + 1];
+  }
+  const int incl = wave_incl_scan_i32(cnt);  // (lanes >= P hold the total)
+  const int n = __builtin_amdgcn_readlane(incl, 63);
+  if (n > E * 64 || k > E * 64) {  // (uniform)
+    if (lane == 0) done[q] = 0;
+    return;
+  }
+  if (lane == 0) done[q] = 1;
+  const int excl = incl - cnt;
+  uint64_t kh[E];
+  int64_t kid[E];
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    const int i = r * 64 + lane;
+    kh[r] = CAND_DROPPED;
+    kid[r] = 0;
+    int u = 0;  // the unit whose list holds flat entry i: the number of lists that end at or before it
+#pragma unroll
+    for (int uu = 0; uu < PMAX; uu++) u += i >= __builtin_amdgcn_readlane(incl, uu) ? 1 : 0;
+    u = u < PMAX ? u : PMAX - 1;  // (i >= n)
+    // (the shuffles stand outside the branch: ds_bpermute returns 0 for a source lane that is switched off, and in a
+    // query's last, partial run of 64 the lanes of its units may be)
+    const int ex_u = __shfl(excl, u, 64), fbu = __shfl(fb, u, 64);
+    if (i < n) {
+      const int j = i - ex_u;
+      const uint64_t *key = fbu < 0 ? b.cand_key + (unit0 + u) * b.cap : b.cand_key2 + (int64_t)fbu * b.cap2;
+      const int64_t *id = fbu < 0 ? b.cand_id + (unit0 + u) * b.cap : b.cand_id2 + (int64_t)fbu * b.cap2;
+      kh[r] = key[j];
+      kid[r] = id[j];
+    }
+  }
+  // candidates handed over as (cluster, posting position): fetch and score (as merge_kernel's staging does), four at a time
+#pragma unroll
+  for (int r0 = 0; r0 < E; r0 += 4) {
+    Posting ps[4];
+    double wq[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int r = r0 + rr;
+      ps[rr] = Posting{0, 0.0};
+      wq[rr] = 0.0;
+      if (kh[r] == CAND_DEFERRED) {
+        ps[rr] = ix.postings[(uint32_t)kid[r]];
+        wq[rr] = b.scan_w[h.scan_begin + (int)((uint64_t)kid[r] >> 32)];
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int r = r0 + rr;
+      if (kh[r] == CAND_DEFERRED) {
+        const double dot = 0.0 + ps[rr].score * wq[rr];  // :92-94
+        double nsq = 0.0 + ps[rr].score * ps[rr].score;  // :95-96
+        if (h.use_norms) nsq = ix.norms[(uint32_t)kid[r]];  // tweets_ann.sql:50-51
+        const double v = normalise(h.alg, dot, nsq, h.l2norm, h.lognorm);
+        kh[r] = v >= h.min_score ? score_key(v) : CAND_DROPPED;  // :125 (false for NaN)
+        kid[r] = ps[rr].id;
+      }
+    }
+    if (r0 + 4 < E) __builtin_amdgcn_sched_barrier(0);
+  }
+  // sort: runs of 64 in registers, then every entry's rank among all runs (ties -- only dropped entries tie -- by run)
+  const int R = (n + 63) >> 6;  // (uniform)
+  ulonglong2 *const runs = s_run[wv];
+  uint64_t mh[E], ml[E];
+  int n_real = 0;
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    const bool real = kh[r] != CAND_DROPPED;
+    mh[r] = real ? kh[r] : 0ull;
+    ml[r] = real ? id_key(kid[r]) : 0ull;
+    n_real += real ? 1 : 0;
+    if (r < R) {
+      wave_sort_desc_k128(mh[r], ml[r]);
+      runs[r * 64 + lane] = make_ulonglong2(mh[r], ml[r]);
+    }
+  }
+  n_real = __builtin_amdgcn_readlane(wave_incl_scan_i32(n_real), 63);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int cnt_out = n_real < k ? n_real : k;
+  const int out_chunk = q / b.out_chunk_q, ql = q - out_chunk * b.out_chunk_q;
+  const int64_t out_shift = out_chunk * b.out_chunk_pitch;  // bytes
+  int64_t *out_ids = (int64_t *)((char *)b.out_ids + out_shift) + (int64_t)ql * b.stride;
+  double *out_scores = (double *)((char *)b.out_scores + out_shift) + (int64_t)ql * b.stride;
+  uint64_t xk_hi = 0, xk_lo = 0;  // the k-th key (0, 0 with fewer than k results)
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    if (r < R) {  // (uniform)
+      const int rank = R == 1 ? lane : rank_among_runs<E>(runs, R, r, lane, mh[r], ml[r]);
+      if (rank < cnt_out) {
+        out_ids[rank] = key_id(ml[r]);
+        out_scores[rank] = key_score(mh[r]);
+      }
+      const unsigned long long at = __ballot(cnt_out == k && k > 0 && rank == k - 1);
+      if (at != 0ull) {
+        const int src = __ffsll((long long)at) - 1;
+        xk_hi = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mh[r] >> 32), src) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mh[r], src);
+        xk_lo = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(ml[r] >> 32), src) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ml[r], src);
+      }
+    }
+  }
+  // candidateScoresMap.size (:102), the exactness proof and the statistics, as merge_kernel
+  const bool inexact = lane < P && k > 0 && (pf_flags & UNIT_TRUNCATED) && key_gt(pf_thi, pf_tlo, xk_hi, xk_lo);
+  const unsigned long long any_inexact = __ballot(inexact);
+  const int msz = __builtin_amdgcn_readlane(wave_incl_scan_i32(pf_unique), 63);
+  const uint32_t t_sum = (uint32_t)__builtin_amdgcn_readlane(wave_incl_scan_i32((int)pf_T), 63);
+  const uint32_t t_max = wave_max_u32(pf_T);
+  if (lane == 0) {
+    if (b.q_stat) b.q_stat[q] = make_uint4(t_max, t_sum, (unsigned)h.n_scan, 0u);
+    ((int32_t *)((char *)b.out_map_sizes + out_shift))[ql] = msz;
+    ((int32_t *)((char *)b.out_counts + out_shift))[ql] = cnt_out;
+    if (any_inexact != 0ull) {
+      const int o = atomicAdd(&b.status[1], 1);
+      b.status[2 + o] = q;  // status[2..] = list of inexact queries
+    }
+  }
+}
+
 // Per-shard results (already exact per shard) -> global top-k.  Shard s's arrays start pitch
 // bytes after shard s-1's (pitch 0 = each array tightly packed shard-major, i.e.
 // ids[n_shards][nq][stride], counts[n_shards][nq]).
@@ -952,12 +1104,24 @@ hipError_t launch_merge(const IndexView &ix, const BatchView &b, const int32_t *
                         hipStream_t stream) {
   if (n_queries <= 0) return hipSuccess;
   // the 512-entry survivor list serves k <= 448; cap2 is the batch's largest k
+  const int32_t *none = nullptr;
+  // a whole batch of small queries (a shard's): one wave per query first -- up to 256 candidates from <= 8 units, or 512
+  // from <= 16 --, then the workgroups for whatever did not fit (normally nothing: they find done[q] set and leave)
+  const bool waves = query_list == nullptr && b.merge_done != nullptr && ix.P <= 16 && b.cap2 <= 448 && b.cap <= 256;
+  const int32_t *skip = waves ? (const int32_t *)b.merge_done : none;
+  if (waves) {
+    const dim3 grid((n_queries + WG / 64 - 1) / (WG / 64));
+    if (ix.P <= 4 && b.cap2 <= 128)
+      hipLaunchKernelGGL((merge_wave_kernel<4, 8>), grid, dim3(WG), 0, stream, ix, b, b.merge_done);
+    else
+      hipLaunchKernelGGL((merge_wave_kernel<8, 16>), grid, dim3(WG), 0, stream, ix, b, b.merge_done);
+  }
   if (ix.P <= 8 && b.cap2 <= 256 && b.cap <= 256)  // a single list (<= 256 entries) fits beside 512 survivors
-    hipLaunchKernelGGL((merge_kernel<256, 640>), dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
+    hipLaunchKernelGGL((merge_kernel<256, 640>), dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list, skip);
   else if (b.cap2 <= 448)
-    hipLaunchKernelGGL((merge_kernel<512, 1728>), dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
+    hipLaunchKernelGGL((merge_kernel<512, 1728>), dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list, skip);
   else
-    hipLaunchKernelGGL((merge_kernel<KMAX, 2048>), dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list);
+    hipLaunchKernelGGL((merge_kernel<KMAX, 2048>), dim3(n_queries), dim3(WG), 0, stream, ix, b, query_list, none);
   return hipGetLastError();
 }
 hipError_t launch_merge_shards(int n_shards, int nq, int stride, int64_t pitch, const int64_t *ids, const double *scores,
