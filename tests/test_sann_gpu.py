@@ -136,6 +136,27 @@ def test_few_partitions_small_k_merge(pkg, oracle, small, P, k):
     index.close()
 
 
+@pytest.mark.parametrize("P", [1, 4, 16])
+def test_wave_merge_beside_workgroup_merge(pkg, oracle, small, P):
+    """merge_wave_kernel (one wave per query: a shard's small queries) beside merge_kernel: per-query k from 3 to 448 and
+    list caps from 5 to 400 give queries with a handful of candidates, queries whose candidates end in a partial run of
+    64, and queries that do not fit a wave's registers and are left to the workgroup kernel; minScore drops handed-over
+    candidates inside either kernel."""
+    co, offs, cids, scs = small
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=P)
+    rng = np.random.default_rng(77 + P)
+    nq = len(offs) - 1
+    for rep in range(2):
+        cfgs = [pkg.SimClustersANNConfig(
+            maxNumResults=int(rng.choice([3, 64, 65, 200, 256, 448])), minScore=float(rng.choice([0.0, 0.0, 0.2])),
+            maxTopTweetsPerCluster=int(rng.choice([5, 40, 400])), maxScanClusters=int(rng.choice([3, 20, 50])),
+            maxTweetCandidateAgeHours=175200, annAlgorithm=pkg.ScoringAlgorithm(int(rng.integers(1, 5))))
+            for _ in range(nq)]
+        out, _ = run_batch(pkg, index, co, offs, cids, scs, cfgs)
+        check_against_oracle(pkg, oracle, co, offs, cids, scs, cfgs, out)
+    index.close()
+
+
 @pytest.mark.parametrize("P", [8, 32])
 def test_more_cut_values_than_the_cache_holds(pkg, oracle, small, P):
     """Six distinct maxTopTweetsPerCluster values in one batch: the index caches cut tables for four, the other
