@@ -295,6 +295,28 @@ def test_tweet_hash_shards_merge_exactly(pkg, oracle, small, S, P):
     torch.cuda.synchronize()
     out = (o_ids.cpu().numpy(), o_sc.cpu().numpy(), o_cnt.cpu().numpy(), o_msz.cpu().numpy())
     check_against_oracle(pkg, oracle, co, offs, cids, scs, cfg, out)
+    # the same lists in another order (not what the library's own merge kernels leave): the merge ranks sorted lists
+    # against each other, but it checks that they are sorted and selects + sorts when they are not
+    cnt = g_cnt.cpu().numpy()
+    gi, gs = g_ids.cpu().numpy().copy(), g_sc.cpu().numpy().copy()
+    rng = np.random.default_rng(3)
+    for s in range(S):
+        for q in range(nq):
+            c = int(cnt[s, q])
+            if q % 3 == 0 or c < 2:
+                continue  # (some queries keep their sorted lists)
+            perm = rng.permutation(c)
+            gi[s, q, :c] = gi[s, q, :c][perm]
+            gs[s, q, :c] = gs[s, q, :c][perm]
+    g_ids.copy_(torch.from_numpy(gi)); g_sc.copy_(torch.from_numpy(gs))
+    o_ids.zero_(); o_sc.zero_(); o_cnt.zero_(); o_msz.zero_()
+    rc = lib.sann_merge_shards(0, None, S, nq, stride, 0, g_ids.data_ptr(), g_sc.data_ptr(), g_cnt.data_ptr(),
+                               g_msz.data_ptr(), batches[0][1].device_k(), o_ids.data_ptr(), o_sc.data_ptr(),
+                               o_cnt.data_ptr(), o_msz.data_ptr())
+    assert rc == 0, lib.sann_last_error()
+    torch.cuda.synchronize()
+    out = (o_ids.cpu().numpy(), o_sc.cpu().numpy(), o_cnt.cpu().numpy(), o_msz.cpu().numpy())
+    check_against_oracle(pkg, oracle, co, offs, cids, scs, cfg, out)
     for ix, qb in batches:
         qb.close(); ix.close()
 
