@@ -1081,13 +1081,19 @@ __global__ __launch_bounds__(WG) void merge_shards_kernel(int n_shards, int nq, 
     }
     __syncthreads();
     const int total = s_off[n_shards];
+    int off[SMAX + 1];  // (registers: the searches below read them at every step)
+#pragma unroll
+    for (int t = 0; t <= SMAX; t++) off[t] = s_off[t];
     if (total <= KMAX) {  // (uniform)
       ulonglong2 *const s_e = reinterpret_cast<ulonglong2 *>(s_keys);
       for (int i = tid; i < total; i += WG) {
         int s = 0;
 #pragma unroll
-        for (int t = 1; t < SMAX; t++) s += (t < n_shards && i >= s_off[t]) ? 1 : 0;
-        const int64_t o = (int64_t)q * stride + (i - s_off[s]);
+        for (int t = 1; t < SMAX; t++) s += i >= off[t] ? 1 : 0;
+        int base_s = 0;
+#pragma unroll
+        for (int t = 1; t < SMAX; t++) base_s = s == t ? off[t] : base_s;
+        const int64_t o = (int64_t)q * stride + (i - base_s);
         s_e[i] = make_ulonglong2(score_key(((const double *)((const char *)scores + s * pitch_ids))[o]),
                                  id_key(((const int64_t *)((const char *)ids + s * pitch_ids))[o]));
       }
@@ -1095,9 +1101,12 @@ __global__ __launch_bounds__(WG) void merge_shards_kernel(int n_shards, int nq, 
       for (int i = tid; i + 1 < total; i += WG) {  // every list in order?
         int s = 0;
 #pragma unroll
-        for (int t = 1; t < SMAX; t++) s += (t < n_shards && i >= s_off[t]) ? 1 : 0;
+        for (int t = 1; t < SMAX; t++) s += i >= off[t] ? 1 : 0;
         const ulonglong2 a = s_e[i], c = s_e[i + 1];
-        if (i + 1 < s_off[s + 1] && !key_gt(a.x, a.y, c.x, c.y)) s_unsorted = 1;
+        int end_s = off[1];
+#pragma unroll
+        for (int t = 1; t < SMAX; t++) end_s = s == t ? off[t + 1] : end_s;
+        if (i + 1 < end_s && !key_gt(a.x, a.y, c.x, c.y)) s_unsorted = 1;
       }
       if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
       __syncthreads();
@@ -1106,12 +1115,12 @@ __global__ __launch_bounds__(WG) void merge_shards_kernel(int n_shards, int nq, 
         const int cnt_out = total < kk ? total : kk;
         int max_len = 0;
 #pragma unroll
-        for (int t = 0; t < SMAX; t++) max_len = max(max_len, s_off[t + 1] - s_off[t]);
+        for (int t = 0; t < SMAX; t++) max_len = max(max_len, off[t + 1] - off[t]);
         const int top = max_len > 0 ? next_pow2(max_len) : 1;
         for (int i = tid; i < total; i += WG) {
           int s = 0;
 #pragma unroll
-          for (int t = 1; t < SMAX; t++) s += (t < n_shards && i >= s_off[t]) ? 1 : 0;
+          for (int t = 1; t < SMAX; t++) s += i >= off[t] ? 1 : 0;
           const ulonglong2 me = s_e[i];
           int pos[SMAX];
 #pragma unroll
@@ -1119,7 +1128,7 @@ __global__ __launch_bounds__(WG) void merge_shards_kernel(int n_shards, int nq, 
           for (int st = top; st >= 1; st >>= 1) {  // (uniform trip count)
 #pragma unroll
             for (int t = 0; t < SMAX; t++) {
-              const int base = s_off[t], len = s_off[t + 1] - base, idx = pos[t] + st - 1;
+              const int base = off[t], len = off[t + 1] - base, idx = pos[t] + st - 1;
               if (idx < len) {
                 const ulonglong2 v = s_e[base + idx];
                 // (entries of different lists never compare equal: tweets belong to one shard; ties by list anyway)
@@ -1128,7 +1137,9 @@ __global__ __launch_bounds__(WG) void merge_shards_kernel(int n_shards, int nq, 
               }
             }
           }
-          int rank = i - s_off[s];
+          int rank = i;
+#pragma unroll
+          for (int t = 1; t < SMAX; t++) rank = s == t ? i - off[t] : rank;
 #pragma unroll
           for (int t = 0; t < SMAX; t++) rank += t != s ? pos[t] : 0;
           if (rank < cnt_out) {
