@@ -957,11 +957,12 @@ static hipError_t launch_one(const IndexView &ix, const BatchView &b, const Fast
 // tables; the per-partition prefix over the clusters runs in LDS, and the rows are written out coalesced.  One
 // round of 1024 workgroups instead of four rounds of one-wave units, each a chain of three dependent trips to memory.
 constexpr int DESC_Q_ITEMS = 4096;  // NSCAN_MAX x 32
-__global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView b, int items_cap, int k_local_floor) {
-  // [c * P + p]; s_len becomes the exclusive prefix.  Sized by the launch for the batch's largest query (12.5 KB at
-  // 50 clusters x 32 partitions): small enough to find room on a CU that is full of unit-kernel workgroups.
+__global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView b, int ld, int k_local_floor) {
+  // s_base / s_len [p * ld + c]; s_len becomes the exclusive prefix.  Sized by the launch for the batch's largest query
+  // (13 KB at 50 clusters x 32 partitions): small enough to find room on a CU that is full of unit-kernel workgroups.
   extern __shared__ uint32_t s_desc[];
-  uint32_t *const s_base = s_desc, *const s_len = s_desc + items_cap;
+  // (tables laid out [p * ld + c] with ld odd: the fill walks p, everything after it walks c -- both free of bank conflicts)
+  uint32_t *const s_base = s_desc, *const s_len = s_desc + ix.P * ld;
   const int tid = threadIdx.x;
   const int q = blockIdx.x;
   {
@@ -1012,8 +1013,8 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
       len = (n > 0 && ix.ranks[base + n - 1] < (uint32_t)M) ? (uint32_t)n
                                                           : (uint32_t)lower_bound_rank(ix.ranks + base, n, (uint32_t)M);
     }
-    s_base[i] = base;
-    s_len[i] = len;
+    s_base[p * ld + c] = base;
+    s_len[p * ld + c] = len;
   }
   __syncthreads();
   // The query-level rule: clusters in key order until k plus a margin postings are covered in ALL the query's partitions
@@ -1027,43 +1028,47 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
     int tot = 0;
     const uint32_t kc = s_okey[tid];
     if (kc != 0u)
-      for (int p = 0; p < P; p++) tot += (int)s_len[(int)s_ocl[tid] * P + p];
+      for (int p = 0; p < P; p++) tot += (int)s_len[p * ld + (int)s_ocl[tid]];
     const int cum = wave_incl_scan_i32(tot);
     const int target = h.k + (h.k / 4 > 32 ? h.k / 4 : 32);
     const unsigned long long ok = __ballot(kc != 0u && cum >= target);
     if (tid == 0) s_qpre = ok != 0ull ? cluster_cut_from_key(s_okey[__ffsll((long long)ok) - 1]) : 0u;
   }
   if (cluster_cut) __syncthreads();  // (uniform)
+  // Per partition: the unit's cut (clusters in key order until kl postings are covered) and the exclusive prefix of the
+  // lengths over the clusters.  One WAVE per partition at a time -- lane = cluster, a DPP prefix sum -- instead of one
+  // thread walking its partition's 50 clusters through dependent LDS reads (32 busy threads of 256, ~12 k clk).  Wave w
+  // owns partitions w, w + 4, ... in both passes, so the second pass may overwrite what the first one read.
+  const int wv = tid >> 6, lane = tid & 63;
   if (cluster_cut) {
     const int kl = unit_kl(h.k, P, k_local_floor);
     const uint32_t qpre = s_qpre;
-    for (int p = tid; p < P; p += 256) {  // clusters in key order until kl postings are covered
+    const uint32_t kc = s_okey[lane];  // (lane = position in key order; keys of 0 sort last: no trusted cluster is left)
+    const int oc = (int)s_ocl[lane];
+    for (int p = wv; p < P; p += 4) {  // (uniform per wave)
+      const int cum = wave_incl_scan_i32(kc != 0u ? (int)s_len[p * ld + oc] : 0);
+      const unsigned long long ok = __ballot(kc != 0u && cum >= kl);
       uint32_t pre = 0u;
-      int cum = 0;
-      for (int i = 0; i < n_scan; i++) {
-        const uint32_t kc = s_okey[i];
-        if (kc == 0u) break;  // (keys of 0 sort last: no trusted cluster is left)
-        cum += (int)s_len[(int)s_ocl[i] * P + p];
-        if (cum >= kl) {
-          pre = cluster_cut_from_key(kc);
-          break;
-        }
-      }
-      b.unit_pre[(int64_t)q * P + p] = pre > qpre ? pre : qpre;
+      if (ok != 0ull) pre = cluster_cut_from_key((uint32_t)__builtin_amdgcn_readlane((int)kc, __ffsll((long long)ok) - 1));
+      if (lane == 0) b.unit_pre[(int64_t)q * P + p] = pre > qpre ? pre : qpre;
     }
   } else {
     for (int p = tid; p < P; p += 256) b.unit_pre[(int64_t)q * P + p] = 0u;
   }
   __shared__ uint32_t s_T[DESC_Q_ITEMS / NSCAN_MAX];  // (P <= 32 here)
-  for (int p = tid; p < P; p += 256) {  // exclusive prefix over the clusters, per partition
-    uint32_t run = 0;
-    for (int c = 0; c < n_scan; c++) {
-      const uint32_t l = s_len[c * P + p];
-      s_len[c * P + p] = run;
-      run += l;
+  for (int p = wv; p < P; p += 4) {  // exclusive prefix over the clusters (n_scan <= 128: two per lane), per partition
+    const int l0 = lane < n_scan ? (int)s_len[p * ld + lane] : 0;
+    const int l1 = lane + 64 < n_scan ? (int)s_len[p * ld + lane + 64] : 0;
+    const int i0 = wave_incl_scan_i32(l0);
+    const int t0 = __builtin_amdgcn_readlane(i0, 63);
+    const int i1 = wave_incl_scan_i32(l1);
+    const int t1 = __builtin_amdgcn_readlane(i1, 63);
+    if (lane < n_scan) s_len[p * ld + lane] = (uint32_t)(i0 - l0);
+    if (lane + 64 < n_scan) s_len[p * ld + lane + 64] = (uint32_t)(t0 + i1 - l1);
+    if (lane == 0) {
+      b.unit_T[(int64_t)q * P + p] = t0 + t1;
+      s_T[p] = (uint32_t)(t0 + t1);
     }
-    b.unit_T[(int64_t)q * P + p] = (int32_t)run;
-    s_T[p] = run;
   }
   __syncthreads();
   // unit-major rows of desc_stride (start, prefix) pairs, padded behind n_scan with (0, T); the query's weights likewise
@@ -1071,18 +1076,18 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
   uint2 *d = reinterpret_cast<uint2 *>(b.desc) + (int64_t)q * P * stride;
   for (int o = tid; o < P * stride; o += 256) {
     const int p = o >> log2s, c = o & (stride - 1);
-    d[o] = c < n_scan ? make_uint2(s_base[c * P + p], s_len[c * P + p]) : make_uint2(0u, s_T[p]);
+    d[o] = c < n_scan ? make_uint2(s_base[p * ld + c], s_len[p * ld + c]) : make_uint2(0u, s_T[p]);
   }
   for (int c = tid; c < stride; c += 256) b.scan_wq[(int64_t)q * stride + c] = c < n_scan ? b.scan_w[scan_begin + c] : 0.0;
 }
 
 hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int max_n_scan, int k_local_floor, hipStream_t stream) {
   if (n_units <= 0) return hipSuccess;
-  const int items_cap = ix.P * (max_n_scan < NSCAN_MAX ? (max_n_scan > 0 ? max_n_scan : 1) : NSCAN_MAX);
+  const int ld = (max_n_scan < NSCAN_MAX ? (max_n_scan > 0 ? max_n_scan : 1) : NSCAN_MAX) | 1;  // (odd: see the kernel)
   // (one workgroup per query from 8 partitions up: the cluster-level cut's sort is then done once per query, not once per
   // unit -- 38 us against 54 for an 8-GPU shard's 65536 units)
   if (ix.P >= 4 && ix.P * NSCAN_MAX <= DESC_Q_ITEMS)
-    hipLaunchKernelGGL(desc_query_kernel, dim3((unsigned)b.nq), dim3(256), (size_t)items_cap * 8, stream, ix, b, items_cap, k_local_floor);
+    hipLaunchKernelGGL(desc_query_kernel, dim3((unsigned)b.nq), dim3(256), (size_t)ix.P * ld * 8, stream, ix, b, ld, k_local_floor);
   else
     hipLaunchKernelGGL(desc_kernel, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, ix, b, n_units, k_local_floor);
   return hipGetLastError();
