@@ -957,25 +957,41 @@ static hipError_t launch_one(const IndexView &ix, const BatchView &b, const Fast
 // tables; the per-partition prefix over the clusters runs in LDS, and the rows are written out coalesced.  One
 // round of 1024 workgroups instead of four rounds of one-wave units, each a chain of three dependent trips to memory.
 constexpr int DESC_Q_ITEMS = 4096;  // NSCAN_MAX x 32
+// QPW = queries per workgroup: 1 (all 256 threads on one query: P >= 16, up to 4096 sub-lists) or 4 (one WAVE per
+// query and no workgroup barrier: a shard's queries have 4 or 8 partitions, 200-400 sub-lists each, and N times as many
+// of them -- 8192 workgroups of mostly idle threads took 30 us).
+template <int QPW>
 __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView b, int ld, int k_local_floor) {
+  constexpr int G = 256 / QPW;  // threads per query
+  constexpr int WPG = G / 64;   // waves per query
   // s_base / s_len [p * ld + c]; s_len becomes the exclusive prefix.  Sized by the launch for the batch's largest query
   // (13 KB at 50 clusters x 32 partitions): small enough to find room on a CU that is full of unit-kernel workgroups.
+  // (ld odd: the fill walks p, everything after it walks c -- both free of bank conflicts)
   extern __shared__ uint32_t s_desc[];
-  // (tables laid out [p * ld + c] with ld odd: the fill walks p, everything after it walks c -- both free of bank conflicts)
-  uint32_t *const s_base = s_desc, *const s_len = s_desc + ix.P * ld;
-  const int tid = threadIdx.x;
-  const int q = blockIdx.x;
+  const int grp = threadIdx.x / G, tid = threadIdx.x % G;  // (tid: within the query's threads)
+  const int P = ix.P;
+  uint32_t *const s_base = s_desc + grp * 2 * P * ld, *const s_len = s_base + P * ld;
+  const int q = blockIdx.x * QPW + grp;
   {
-    const int g = blockIdx.x * 256 + tid;  // per-run state (see desc_kernel)
+    const int g = blockIdx.x * 256 + threadIdx.x;  // per-run state (see desc_kernel)
     if (g < b.nq + 2) b.status[g] = 0;
   }
-  const int P = ix.P;
+  if (q >= b.nq) return;  // (QPW > 1: whole waves, and nothing below synchronises across a query's threads' workgroup)
+  // a query's threads meet: the workgroup's barrier, or -- one wave per query -- just the order of the wave's own LDS traffic
+  auto meet = [&]() {
+    if constexpr (QPW == 1) __syncthreads();
+    else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  };
   const int M = b.hdr[q].M;
   const int scan_begin = b.hdr[q].scan_begin;
   const int n_scan = b.hdr[q].n_scan;
-  for (int p = tid; p < P; p += 256) b.unit_fb[(int64_t)q * P + p] = -1;
+  for (int p = tid; p < P; p += G) b.unit_fb[(int64_t)q * P + p] = -1;
   if (n_scan > NSCAN_MAX) {  // the unit kernel sends such units to the general path
-    for (int p = tid; p < P; p += 256) {
+    for (int p = tid; p < P; p += G) {
       b.unit_T[(int64_t)q * P + p] = 0;
       b.unit_pre[(int64_t)q * P + p] = 0u;
     }
@@ -983,8 +999,10 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
   }
   // cluster-level cut: the order of the query's clusters by key is the same for all of its units -- sorted once, by
   // wave 0 (lane c = cluster c), while the other waves already chase the sub-list descriptors
-  __shared__ uint32_t s_okey[64];  // sorted position i: the cluster's key ...
-  __shared__ uint8_t s_ocl[64];    // ... and the cluster
+  __shared__ uint32_t s_okey_all[QPW][64];  // sorted position i: the cluster's key ...
+  __shared__ uint8_t s_ocl_all[QPW][64];    // ... and the cluster
+  uint32_t *const s_okey = s_okey_all[grp];
+  uint8_t *const s_ocl = s_ocl_all[grp];
   const QueryHdr h = b.hdr[q];
   const bool cluster_cut = query_has_cluster_cut(h);  // (uniform)
   if (cluster_cut && tid < 64) {
@@ -999,8 +1017,8 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
 #pragma unroll
   for (int j = 0; j < 4; j++)
     if (b.cut_M[j] == M) cut = b.cut[j];
-  const int n_items = n_scan * P;  // <= items_cap
-  for (int i = tid; i < n_items; i += 256) {
+  const int n_items = n_scan * P;
+  for (int i = tid; i < n_items; i += G) {
     const int c = i >> ix.log2P, p = i & (P - 1);
     const int row = b.scan_row[scan_begin + c];
     const uint32_t base = ix.sub_offsets[(int64_t)row * P + p];
@@ -1016,14 +1034,14 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
     s_base[p * ld + c] = base;
     s_len[p * ld + c] = len;
   }
-  __syncthreads();
+  meet();
   // The query-level rule: clusters in key order until k plus a margin postings are covered in ALL the query's partitions
   // together.  A cluster's single-cluster candidates share one key, so a cut below that cluster keeps every candidate
   // that can reach the top k whichever partitions they fell into -- no per-unit allowance for the spread (unit_kl: the
   // share plus five sigma) is needed, and a query hands ~800 candidates to its merge instead of ~1500.  A unit takes the
   // stricter of the two cuts.  (Postings that filters or duplicates then remove are what the margin, the unit kernel's
   // data-dependent re-cut and, in the end, the merge's proof are for.)
-  __shared__ uint32_t s_qpre;
+  __shared__ uint32_t s_qpre_all[QPW];
   if (cluster_cut && tid < 64) {
     int tot = 0;
     const uint32_t kc = s_okey[tid];
@@ -1032,20 +1050,20 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
     const int cum = wave_incl_scan_i32(tot);
     const int target = h.k + (h.k / 4 > 32 ? h.k / 4 : 32);
     const unsigned long long ok = __ballot(kc != 0u && cum >= target);
-    if (tid == 0) s_qpre = ok != 0ull ? cluster_cut_from_key(s_okey[__ffsll((long long)ok) - 1]) : 0u;
+    if (tid == 0) s_qpre_all[grp] = ok != 0ull ? cluster_cut_from_key(s_okey[__ffsll((long long)ok) - 1]) : 0u;
   }
-  if (cluster_cut) __syncthreads();  // (uniform)
+  if (cluster_cut) meet();  // (uniform)
   // Per partition: the unit's cut (clusters in key order until kl postings are covered) and the exclusive prefix of the
   // lengths over the clusters.  One WAVE per partition at a time -- lane = cluster, a DPP prefix sum -- instead of one
-  // thread walking its partition's 50 clusters through dependent LDS reads (32 busy threads of 256, ~12 k clk).  Wave w
-  // owns partitions w, w + 4, ... in both passes, so the second pass may overwrite what the first one read.
+  // thread walking its partition's 50 clusters through dependent LDS reads.  A wave owns the same partitions in both
+  // passes, so the second pass may overwrite what the first one read.
   const int wv = tid >> 6, lane = tid & 63;
   if (cluster_cut) {
     const int kl = unit_kl(h.k, P, k_local_floor);
-    const uint32_t qpre = s_qpre;
+    const uint32_t qpre = s_qpre_all[grp];
     const uint32_t kc = s_okey[lane];  // (lane = position in key order; keys of 0 sort last: no trusted cluster is left)
     const int oc = (int)s_ocl[lane];
-    for (int p = wv; p < P; p += 4) {  // (uniform per wave)
+    for (int p = wv; p < P; p += WPG) {  // (uniform per wave)
       const int cum = wave_incl_scan_i32(kc != 0u ? (int)s_len[p * ld + oc] : 0);
       const unsigned long long ok = __ballot(kc != 0u && cum >= kl);
       uint32_t pre = 0u;
@@ -1053,10 +1071,11 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
       if (lane == 0) b.unit_pre[(int64_t)q * P + p] = pre > qpre ? pre : qpre;
     }
   } else {
-    for (int p = tid; p < P; p += 256) b.unit_pre[(int64_t)q * P + p] = 0u;
+    for (int p = tid; p < P; p += G) b.unit_pre[(int64_t)q * P + p] = 0u;
   }
-  __shared__ uint32_t s_T[DESC_Q_ITEMS / NSCAN_MAX];  // (P <= 32 here)
-  for (int p = wv; p < P; p += 4) {  // exclusive prefix over the clusters (n_scan <= 128: two per lane), per partition
+  __shared__ uint32_t s_T_all[QPW][DESC_Q_ITEMS / NSCAN_MAX];  // (P <= 32 here)
+  uint32_t *const s_T = s_T_all[grp];
+  for (int p = wv; p < P; p += WPG) {  // exclusive prefix over the clusters (n_scan <= 128: two per lane), per partition
     const int l0 = lane < n_scan ? (int)s_len[p * ld + lane] : 0;
     const int l1 = lane + 64 < n_scan ? (int)s_len[p * ld + lane + 64] : 0;
     const int i0 = wave_incl_scan_i32(l0);
@@ -1070,15 +1089,15 @@ __global__ __launch_bounds__(256) void desc_query_kernel(IndexView ix, BatchView
       s_T[p] = (uint32_t)(t0 + t1);
     }
   }
-  __syncthreads();
+  meet();
   // unit-major rows of desc_stride (start, prefix) pairs, padded behind n_scan with (0, T); the query's weights likewise
   const int stride = b.desc_stride, log2s = stride == 64 ? 6 : 7;
   uint2 *d = reinterpret_cast<uint2 *>(b.desc) + (int64_t)q * P * stride;
-  for (int o = tid; o < P * stride; o += 256) {
+  for (int o = tid; o < P * stride; o += G) {
     const int p = o >> log2s, c = o & (stride - 1);
     d[o] = c < n_scan ? make_uint2(s_base[p * ld + c], s_len[p * ld + c]) : make_uint2(0u, s_T[p]);
   }
-  for (int c = tid; c < stride; c += 256) b.scan_wq[(int64_t)q * stride + c] = c < n_scan ? b.scan_w[scan_begin + c] : 0.0;
+  for (int c = tid; c < stride; c += G) b.scan_wq[(int64_t)q * stride + c] = c < n_scan ? b.scan_w[scan_begin + c] : 0.0;
 }
 
 hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int max_n_scan, int k_local_floor, hipStream_t stream) {
@@ -1086,8 +1105,12 @@ hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int
   const int ld = (max_n_scan < NSCAN_MAX ? (max_n_scan > 0 ? max_n_scan : 1) : NSCAN_MAX) | 1;  // (odd: see the kernel)
   // (one workgroup per query from 8 partitions up: the cluster-level cut's sort is then done once per query, not once per
   // unit -- 38 us against 54 for an 8-GPU shard's 65536 units)
-  if (ix.P >= 4 && ix.P * NSCAN_MAX <= DESC_Q_ITEMS)
-    hipLaunchKernelGGL(desc_query_kernel, dim3((unsigned)b.nq), dim3(256), (size_t)ix.P * ld * 8, stream, ix, b, ld, k_local_floor);
+  if (ix.P >= 4 && ix.P * NSCAN_MAX <= DESC_Q_ITEMS) {
+    if (ix.P <= 8)  // four queries per workgroup, one wave each
+      hipLaunchKernelGGL((desc_query_kernel<4>), dim3((unsigned)((b.nq + 3) / 4)), dim3(256), (size_t)4 * ix.P * ld * 8, stream, ix, b, ld, k_local_floor);
+    else
+      hipLaunchKernelGGL((desc_query_kernel<1>), dim3((unsigned)b.nq), dim3(256), (size_t)ix.P * ld * 8, stream, ix, b, ld, k_local_floor);
+  }
   else
     hipLaunchKernelGGL(desc_kernel, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, ix, b, n_units, k_local_floor);
   return hipGetLastError();
