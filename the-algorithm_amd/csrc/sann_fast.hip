@@ -594,7 +594,8 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
           const long long my = s_Mid[m];
           const int myseq = s_Mseq[m];
           int cnt = 0, rep = myseq;
-          for (int e2 = 0; e2 < nm; e2++) {
+#pragma unroll 4
+          for (int e2 = 0; e2 < nm; e2++) {  // (unrolled: four LDS round trips in flight, not one after the other)
             const bool same = s_Mid[e2] == my;
             const int se = s_Mseq[e2];
             cnt += same ? 1 : 0;
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
               for (int rr = 0; rr < cnt; rr++) {  // ascending cluster sequence
                 int best = 0x7fffffff;
                 double bs = 0.0;
+#pragma unroll 4
                 for (int e2 = 0; e2 < nm; e2++) {
                   const int se = s_Mseq[e2];
                   if (s_Mid[e2] == my && se > last && se < best) { best = se; bs = s_Msc[e2]; }
