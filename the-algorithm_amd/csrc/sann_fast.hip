@@ -584,12 +584,63 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
     if (nm > MCAP) {
       overflow = true;
       if (tid == 0) s_ctl[CTL_BAD] = 8;  // (diagnostics: the match list overflowed)
+    } else if (nm > 12 && nm <= 64) {
+      // A duplicate-heavy corpus (1M tweets under 144k clusters: every unit, 40-60 entries): the entries are SORTED by
+      // (tweet id, cluster sequence) in wave 0's registers -- groups become runs of neighbouring lanes, a run's first
+      // lane is its representative and walks the run for its sums (ascending cluster sequence: the reference's order).
+      // The pairwise comparison below costs nm^2 dependent LDS reads: 18 k of such a unit's 40 k cycles.
+      if (tid < 64) {
+        const bool have = tid < nm;
+        uint64_t kh = have ? id_key(s_Mid[tid]) : 0ull;  // descending id_key = ascending id
+        uint64_t kl = have ? ~(uint64_t)(((uint32_t)s_Mseq[tid] << 6) | (uint32_t)tid) : 0ull;  // (never 0 for an entry)
+        wave_sort_desc_k128(kh, kl);
+        const bool live = (kh | kl) != 0ull;
+        const uint32_t pk = (uint32_t)~kl;  // cluster sequence << 6 | entry
+        const int ee = (int)(pk & 63u);
+        const uint64_t prev = __shfl_up((unsigned long long)kh, 1, 64);
+        const bool start = live && (tid == 0 || prev != kh);
+        const unsigned long long sm = __ballot(start);
+        const int n_ent = __popcll(__ballot(live));
+        const unsigned long long above = tid == 63 ? 0ull : (sm >> (tid + 1));
+        const int len = start ? (above != 0ull ? __ffsll((long long)above) : n_ent - tid) : 0;
+        const int role = !live ? 0 : (start ? (len >= 2 ? 1 : 0) : 2);
+        const int max_len = (int)wave_max_u32((uint32_t)len);
+        double dot = 0.0, nsq = 0.0;
+        for (int j = 0; j < max_len; j++) {  // (uniform)
+          const uint32_t pj = (uint32_t)__shfl((int)pk, tid + j < 64 ? tid + j : 63, 64);
+          if (role == 1 && j < len) {
+            const double bs = s_Msc[pj & 63u];
+            dot = dot + bs * s_w[pj >> 6];  // :92-94
+            nsq = nsq + bs * bs;            // :95-96
+          }
+        }
+        if (live) {
+          if (role == 1) {
+            if constexpr (NORMS) nsq = use_norms ? s_Mnrm[ee] : nsq;  // one norm per tweet, not a sum over clusters
+            s_Mdot[ee] = dot;
+            s_Mnsq[ee] = nsq;
+          }
+          s_Mrole[ee] = role;
+        }
+      }
+      __syncthreads();
+      STAMP(10);  // groups settled
+      int folded = 0;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int role = mi[u] >= 0 ? s_Mrole[mi[u]] : 0;
+        seq[u] = role == 1 ? (0x10000 | mi[u]) : (role == 2 ? -1 : seq[u]);
+        folded += __popcll(__ballot(role == 2));
+      }
+      if ((tid & 63) == 0 && folded) {
+        atomicSub(&s_ctl[CTL_LIVE], folded);
+        atomicAdd(&s_ctl[CTL_FOLD], folded);
+      }
+      __syncthreads();
     } else {
       {
-        // one thread per match-list entry, ids compared inside M (a handful of entries on a large corpus -- mostly
-        // Bloom false positives -- up to MCAP on a duplicate-heavy one).  (A wave-sorted variant for 13..64 entries
-        // was dropped: its eight-wide register groups were what pushed hipcc into spilling, and ROCm 7.2 places
-        // VGPR spill stores in front of the exec-mask restore of a join block -- lanes then reload garbage.)
+        // one thread per match-list entry, ids compared inside M (a handful of entries on a large corpus, or more than a
+        // wave holds)
         for (int m = tid; m < nm; m += WG) {
           const long long my = s_Mid[m];
           const int myseq = s_Mseq[m];
