@@ -218,6 +218,48 @@ def test_heavy_duplication_and_explicit_order(pkg, oracle):
     index.close()
 
 
+@pytest.mark.parametrize("P", [4, 16])
+def test_moderate_duplication_sorted_match_list(pkg, oracle, P):
+    """A few dozen match-list entries per unit -- the regime of a duplicate-heavy corpus (1M tweets under 144k clusters), where
+    the unit kernel sorts the list by (tweet id, cluster sequence) in registers and settles the groups run by run: 24 popular
+    tweets sit in 2 to 5 of the 12 scanned clusters each (groups of every size, ~15-45 entries per unit at P = 4), everything else
+    in one."""
+    rng = np.random.default_rng(31)
+    n_c, per = 12, 220
+    popular = ((np.arange(24, dtype=np.int64) * 104729 + 777) << 22) + 5
+    lists, nxt = {}, 1
+    member = {int(t): set(rng.choice(np.arange(1, n_c + 1), size=int(rng.integers(2, 6)), replace=False).tolist()) for t in popular}
+    for c in range(1, n_c + 1):
+        mine = [t for t in popular.tolist() if c in member[t]]
+        own = ((np.arange(nxt, nxt + per - len(mine), dtype=np.int64) * 15485863) << 22) + 9
+        nxt += per
+        t = rng.permutation(np.concatenate([np.array(mine, np.int64), own]))
+        s = np.sort(np.exp(rng.normal(-2, 1, len(t))))[::-1]
+        lists[c] = list(zip(t.tolist(), s.tolist()))
+    index = pkg.ClusterTweetIndex.from_map(lists, n_partitions=P)
+    cs = sorted(lists)
+
+    class Co:
+        now_ms = 1_700_000_000_000
+        cluster_ids = np.array(cs, np.int32)
+        list_offsets = np.concatenate([[0], np.cumsum([len(lists[c]) for c in cs])]).astype(np.int64)
+        tweet_ids = np.concatenate([np.array([x[0] for x in lists[c]], np.int64) for c in cs])
+        scores = np.concatenate([np.array([x[1] for x in lists[c]], np.float64) for c in cs])
+
+    nq = 6
+    offs = np.arange(0, (nq + 1) * n_c, n_c, dtype=np.int64)
+    cids = np.tile(np.arange(1, n_c + 1, dtype=np.int32), nq)
+    scs = np.exp(rng.normal(0, 1, nq * n_c))
+    for alg in (1, 2, 3, 4):
+        cfg = pkg.SimClustersANNConfig(maxNumResults=100, maxTopTweetsPerCluster=per, maxScanClusters=n_c,
+                                       maxTweetCandidateAgeHours=175200, annAlgorithm=pkg.ScoringAlgorithm(alg))
+        out, st = run_batch(pkg, index, Co, offs, cids, scs, cfg)
+        check_against_oracle(pkg, oracle, Co, offs, cids, scs, cfg, out)
+        # (the fast path's own duplicate resolution, not the general path's table)
+        assert st.n_fallback_units == 0, (st.n_fallback_units, st.n_units)
+    index.close()
+
+
 def test_edge_cases(pkg, oracle, small):
     co, offs, cids, scs = small
     index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=4)
