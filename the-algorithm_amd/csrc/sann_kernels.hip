@@ -10,13 +10,20 @@
 //                        Always correct for any size / duplication; it is the fallback of the
 //                        LDS fast path (sann_fast.hip) and the first path that was parity-green.
 //   merge_kernel         one workgroup per query: exact top-k over the units' candidates under
-//                        the total order (score desc by Double.compare, tweet id asc).  The units'
-//                        lists are streamed through LDS in chunks (a tournament: each chunk is cut
-//                        against the running survivors by an adaptive 128-bit radix select), the
-//                        <= 512 / 1024 survivors are bitonic-sorted as packed 128-bit keys.  Also
-//                        proves the result exact: a unit that withheld candidates below its
-//                        threshold is harmless iff that threshold is <= the global k-th key.
-//   merge_shards_kernel  the same merge over all-gathered per-shard results.
+//                        the total order (score desc by Double.compare, tweet id asc).  While it stages
+//                        the units' lists in LDS it fetches the posting of every candidate a fast unit
+//                        handed over as (cluster, posting position) and computes its exact fp64 score
+//                        (:92-96, :111-125).  A cut from a sorted sample (radix passes as fallback) leaves
+//                        <= 512 / 1024 survivors, sorted by in-register wave sorts of 64-entry runs and
+//                        pairwise merges; more candidates than the staging area holds go through it in
+//                        rounds (a tournament).  Also proves the result exact: a unit that withheld
+//                        candidates below its threshold is harmless iff that threshold is <= the global
+//                        k-th key.
+//   merge_wave_kernel    the same merge for a shard's small queries (<= 16 units, <= 512 candidates):
+//                        one WAVE per query, candidates in registers, no workgroup barrier.
+//   merge_shards_kernel  the owner's merge of the per-shard results the all-to-all delivered: sorted
+//                        lists are ranked against each other (a lock-step binary search per list);
+//                        unsorted input is selected and sorted.
 //
 // Compiled with -ffp-contract=off (see sann_math.h).
 #include <hip/hip_runtime.h>
