@@ -1,40 +1,39 @@
 // sann_fast.hip -- fast path of the (query, partition) work unit, gfx950.
 //
-// Two kernels.
-//
-// desc_kernel   one thread per (query, scanned cluster, partition): sub-list start and the number
-//               of its postings with rank < M (binary search in `ranks`; the `i < min(size, M)` cut
-//               of ApproximateCosineSimilarity.scala:87).  The lookups are a chain of dependent
-//               loads (scan_row -> sub_offsets -> ranks); doing them here, millions of independent
-//               threads wide, keeps that chain out of the unit kernel, whose own chain is then just
-//               descriptors -> postings.
+// desc_query_kernel / desc_kernel   per (query, scanned cluster, partition): sub-list start and the number of its postings
+//               with rank < M (a cached cut table, or a binary search in `ranks`; the `i < min(size, M)` cut of
+//               ApproximateCosineSimilarity.scala:87), the exclusive prefix over the clusters, and for the cosine forms
+//               the cut of every unit (per unit and per query, see 3 below).  The lookups are a chain of dependent loads
+//               (scan_row -> sub_offsets -> cut / ranks); doing them here keeps that chain out of the unit kernel.  Rows
+//               and cluster weights are written at a FIXED stride (64 / 128 entries, padded), so that the unit kernel
+//               finds them from its block index alone.  One workgroup per query (P >= 16), one wave per query (P = 4, 8:
+//               a shard's queries), or one wave per unit (P < 4).
 //
 // unit_fast_kernel   one workgroup = one unit; the unit's postings live in REGISTERS (U per thread: an fp32 copy of
-//               the score and the cluster's sequence number -- the fp64 posting is read again only for survivors).
-//               Measured instruction-issue / latency bound (profiles/r02_pmc_summary.txt), so everything is arranged
-//               to spend few instructions per posting and to keep eight workgroups on a CU (<= 64 VGPRs, 20 KB LDS):
-//   1. descriptors  coalesced read of the unit's (start, prefix) row; byte map flat posting index -> cluster;
-//                   per-cluster constants (fp64 weight, fp32 weight, and for the cosine forms the fp32 KEY of a
-//                   single-cluster candidate: (s w) / sqrt(s s) = w, so such a candidate needs no arithmetic)
+//               the score, the cluster's sequence number and a hash of the id -- the fp64 posting is read again only for
+//               survivors, by the MERGE kernel).  What bounds it is the time a workgroup holds its slot -- a chain of
+//               dependent memory trips -- at eight workgroups per CU (<= 64 VGPRs, 20 KB LDS, <= 80 SGPRs):
+//   1. descriptors  header, (start, prefix) row, cluster weights and posting count in ONE trip; byte map flat posting
+//                   index -> cluster; per-cluster constants (fp64 weight, fp32 weight, and for the cosine forms the fp32
+//                   KEY of a single-cluster candidate: (s w) / sqrt(s s) = w, so such a candidate needs no arithmetic)
 //   2. gather       one 16-B global load per posting, consecutive lanes = consecutive postings of a sub-list; all of a
 //                   thread's loads are issued (inline asm: hipcc otherwise waits after each) before the single wait;
 //                   age window and source-tweet filters (:90-91)
-//   5a'. cluster cut  (cosine forms, while the loads are in flight) wave 0 sorts the clusters by that key and scans
-//                   their posting counts: the cut is a property of the descriptors, known before any posting arrives
-//   3. duplicates   a tweet can sit in several scanned clusters (all its postings are in this unit by construction of
-//                   the partition hash).  Each posting ORs three hash bits into one 64-bit word of a blocked Bloom
+//   3. cluster cut  (cosine forms) the cut is a property of the descriptors: read from the descriptor kernel's output
+//   3a/b. duplicates  a tweet can sit in several scanned clusters (all its postings are in this unit by construction of
+//                   the partition hash).  Each posting ORs four hash bits into one 64-bit word of a blocked Bloom
 //                   filter with ONE LDS atomic; finding all already set flags the id.  Units with a flag (one in
-//                   five at the benchmark's shape) load their postings again and resolve the flagged ids through a
-//                   small match list, groups summed by one thread in cluster order, so fp64 sums follow the
+//                   three at the benchmark's shape) look their hashes up in the flagged filter, fetch the matching
+//                   postings again and resolve the flagged ids through a small match list -- pairwise for a handful of
+//                   entries, sorted in registers for 13..64 --, groups summed in cluster order, so fp64 sums follow the
 //                   reference's accumulation order (:83-100) whatever the timing.
 //   4. keys         APPROXIMATE fp32 score per live candidate (|approx/exact - 1| <= EPS), as an order-preserving u32
-//   5a. data cut    (other forms, or when 5a' kept too few) the kl-th largest of the 256 per-thread maxima, found by
-//                   an in-register bitonic sort per wave (DPP / permlane swaps) and a rank search in LDS
-//   5b. compact     survivors (key >= cut) into LDS as (cluster, posting position): one LDS atomic per wave
-//   6. exact        the survivors (tens, out of ~1250) are fetched again -- L2 hits -- and only they get the exact fp64
-//                   normalisation (:111-119, two divisions and a square root), `>= minScore` (:125), the monotone
-//                   64-bit key; emit those with key >= key(theta), theta = cut (1 + 2 EPS): an exact upper set of
-//                   the unit, plus key(theta) so that the merge can prove the global top-k exact.
+//   5a. data cut    (other forms, or when filters thinned what 3 counted on) the kl-th largest of the 256 per-thread
+//                   maxima, found by an in-register bitonic sort per wave (DPP / permlane swaps) and a rank search in LDS
+//   5b. compact     survivors (key >= cut) into LDS as (cluster, flat posting index): one LDS atomic per wave
+//   6. hand over    the survivors (tens, out of ~1250) leave as (cluster, posting position) with key(theta), theta =
+//                   cut (1 + 2 EPS); the merge kernel computes their exact fp64 scores (:111-125) and proves the global
+//                   top-k exact against the units' thetas.  Representatives of multi-cluster tweets are finished here.
 //
 // Units that do not fit (too many clusters / postings / flagged ids / survivors, scores outside the fp32 range) flag
 // UNIT_OVERFLOW and are re-run by unit_general_kernel.
