@@ -38,6 +38,8 @@ extern "C" {
 #define ANNC_EFORMAT -3   /* not what the IDL says (wrong type for a known field, required field missing, ...) */
 #define ANNC_ESPACE -4    /* output buffer too small; *len tells the size needed where applicable */
 #define ANNC_EIO -5       /* file could not be read / written */
+#define ANNC_ENOMEM -6    /* host allocation failed */
+#define ANNC_EINTERNAL -7 /* an unexpected C++ exception was caught at the ABI */
 
 const char *ann_codec_last_error(void);
 

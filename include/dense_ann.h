@@ -31,6 +31,8 @@ extern "C" {
 #define DANN_EINVAL 1
 #define DANN_EDEVICE 2
 #define DANN_ELIMIT 3
+#define DANN_ENOMEM 4    /* host allocation failed */
+#define DANN_EINTERNAL 5 /* an unexpected C++ exception was caught at the ABI; the message says which */
 
 /* ann_common.thrift:16-19 */
 #define DANN_METRIC_L2 0

@@ -35,6 +35,8 @@ extern "C" {
 #define HNSW_EINVAL 1
 #define HNSW_EDEVICE 2
 #define HNSW_ELIMIT 3
+#define HNSW_ENOMEM 4    /* host allocation failed */
+#define HNSW_EINTERNAL 5 /* an unexpected C++ exception was caught at the ABI; the message says which */
 
 /* ann_common.thrift:16-19 */
 #define HNSW_METRIC_L2 0

@@ -26,6 +26,8 @@ extern "C" {
 #define RSX_OK 0
 #define RSX_EINVAL 1
 #define RSX_EDEVICE 2
+#define RSX_ENOMEM 3    /* host allocation failed */
+#define RSX_EINTERNAL 4 /* an unexpected C++ exception was caught at the ABI; the message says which */
 
 /* ScoringAlgorithm, score.thrift:14-22 */
 #define RSX_PAIR_DOT_PRODUCT 1

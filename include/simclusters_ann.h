@@ -119,8 +119,9 @@ typedef struct sann_batch_stats {
 const char *sann_last_error(void);
 /* Environment advice the library has for its process, "" when none.  Today: batches in flight (sann_batch_run_after,
  * sann_get_tweet_candidates from several threads) need GPU_MAX_HW_QUEUES >= 8 -- streams that share a hardware queue
- * execute in order and the overlap is silently lost.  The library sets the variable when it is loaded if the process
- * has not; this returns (and stderr shows, once) a message if the process chose fewer. */
+ * execute in order and the overlap is silently lost.  The variable belongs to the process (the HIP runtime reads it once,
+ * when it initialises): the launcher / JVM shim exports it before the process starts; the library never
+ * changes the environment.  This returns (and stderr shows, once) a message when the process runs with fewer. */
 const char *sann_runtime_advice(void);
 /* Library self-description, e.g. "simclusters_amd 0.1 gfx950". */
 const char *sann_version(void);
@@ -235,7 +236,8 @@ int sann_index_destroy(sann_index_t *index);
  *   configs[n_configs]  n_configs is 1 (shared) or nq.
  *   scan_offsets[nq+1], scan_cluster_ids   (both may be NULL)
  *       the keys of clusterTweetsMap in the iteration order the caller wants the accumulation
- *       to follow.  NULL reproduces SimClustersANNCandidateSource.fetchCandidates:
+ *       to follow (given together or not at all: one without the other is SANN_EINVAL).
+ *       NULL reproduces SimClustersANNCandidateSource.fetchCandidates:
  *       sourceEmbedding.truncate(maxScanClusters).getClusterIds().toSet, iterated in ascending
  *       cluster id (the reference's order is JVM hash order).
  *   now_ms  the value of Time.now (ApproximateCosineSimilarity.scala:65).
@@ -306,6 +308,13 @@ int sann_debug_gather_probe(sann_batch_t *batch, int32_t mode, int32_t wgs_per_c
 /* Debug: per-unit arrays of the last run ([nq * n_partitions] each; any may be NULL): distinct tweets accumulated,
  * candidates emitted, UNIT_* flags, postings scanned. */
 int sann_debug_unit_arrays(sann_batch_t *batch, int32_t *unit_unique, int32_t *cand_cnt, uint32_t *unit_flags, int32_t *unit_T);
+/* Test hook, pure host code (no HIP call): what sann_batch_finish decides from a device-written status block -- n_over
+ * overflowed unit ids and n_inexact unproven query ids of a batch of nq queries x n_partitions units.  Counts and ids are
+ * range-checked exactly as sann_batch_finish checks them: anything outside the batch's shape is SANN_EINTERNAL (never an
+ * exception, an abort or a wild write).  *n_units_out / *n_queries_out = units the general path would re-run and queries
+ * whose merge would be repeated. */
+int sann_debug_plan_slow_tail(int32_t nq, int32_t n_partitions, int32_t n_over, const int32_t *over_units, int32_t n_inexact,
+                              const int32_t *inexact_queries, int32_t *n_units_out, int32_t *n_queries_out);
 /* Debug: after sann_batch_run + a device sync and BEFORE sann_batch_finish, histogram of why fast
  * units overflowed: [1] too many scanned clusters, [2] too many postings, [3] too many
  * multi-cluster tweets, [4] score outside the fp32 pre-filter range / hash clash, [5] tie group. */
@@ -387,7 +396,8 @@ int sann_owner_message_layout(int32_t queries_per_owner, int32_t stride, int64_t
 /* Make the merge kernel write the final results into caller-owned device buffers (e.g. torch
  * tensors that feed an all-gather) instead of the batch's own; pass four NULLs to unbind.
  * Sizes: int64[nq*stride], double[nq*stride], int32[nq], int32[nq], stride as reported by
- * sann_batch_device_results. */
+ * sann_batch_device_results.  The binding survives sann_batch_reset; the batch remembers the shape (nq, stride) it had
+ * when it was bound, and a reset to more queries or a larger maxNumResults is refused with SANN_EINVAL. */
 int sann_batch_bind_outputs(sann_batch_t *batch, void *d_ids, void *d_scores, void *d_counts, void *d_map_sizes);
 
 /* The same, for results that leave in one all-to-all: query q is written into chunk q / queries_per_chunk (the

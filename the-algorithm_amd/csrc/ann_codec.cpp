@@ -12,6 +12,9 @@
 #include <unordered_map>
 #include <vector>
 
+#include "abi_guard.h"
+#define ABI_CATCH catch (...) { return abi_guard::caught(fail, ANNC_ENOMEM, ANNC_EINTERNAL); }
+
 namespace {
 
 thread_local std::string g_err;
@@ -338,38 +341,38 @@ extern "C" {
 
 const char *ann_codec_last_error(void) { return g_err.c_str(); }
 
-int sann_wire_encode_query(const sann_wire_query_t *q, uint8_t *buf, int64_t cap, int64_t *len) {
+int sann_wire_encode_query(const sann_wire_query_t *q, uint8_t *buf, int64_t cap, int64_t *len) try {
   if (int rc = check_query(q)) return rc;
   W w(buf, cap);
   write_query(w, *q);
   return w.finish(len);
-}
+} ABI_CATCH
 
-int sann_wire_decode_query(const uint8_t *buf, int64_t n, sann_wire_query_t *q, int64_t *consumed) {
+int sann_wire_decode_query(const uint8_t *buf, int64_t n, sann_wire_query_t *q, int64_t *consumed) try {
   if (!buf || n < 0 || !q) return fail(ANNC_EINVAL, "NULL argument");
   R r(buf, n);
   if (int rc = read_query(r, q)) return rc;
   if (consumed) *consumed = r.o;
   return ANNC_OK;
-}
+} ABI_CATCH
 
-int sann_wire_encode_candidates(int32_t count, const int64_t *ids, const double *scores, uint8_t *buf, int64_t cap, int64_t *len) {
+int sann_wire_encode_candidates(int32_t count, const int64_t *ids, const double *scores, uint8_t *buf, int64_t cap, int64_t *len) try {
   if (count < 0 || (count > 0 && (!ids || !scores))) return fail(ANNC_EINVAL, "bad candidate arrays");
   W w(buf, cap);
   write_candidates(w, count, ids, scores);
   return w.finish(len);
-}
+} ABI_CATCH
 
 int sann_wire_decode_candidates(const uint8_t *buf, int64_t n, int32_t cap, int64_t *ids, double *scores, int32_t *count,
-                                int64_t *consumed) {
+                                int64_t *consumed) try {
   if (!buf || n < 0) return fail(ANNC_EINVAL, "NULL argument");
   R r(buf, n);
   if (int rc = read_candidates(r, cap, ids, scores, count)) return rc;
   if (consumed) *consumed = r.o;
   return ANNC_OK;
-}
+} ABI_CATCH
 
-int sann_wire_encode_call(int32_t seqid, const sann_wire_query_t *q, uint8_t *buf, int64_t cap, int64_t *len) {
+int sann_wire_encode_call(int32_t seqid, const sann_wire_query_t *q, uint8_t *buf, int64_t cap, int64_t *len) try {
   if (int rc = check_query(q)) return rc;
   W w(buf, cap);
   write_message_begin(w, M_CALL, seqid);
@@ -377,9 +380,9 @@ int sann_wire_encode_call(int32_t seqid, const sann_wire_query_t *q, uint8_t *bu
   write_query(w, *q);
   w.stop();
   return w.finish(len);
-}
+} ABI_CATCH
 
-int sann_wire_decode_call(const uint8_t *buf, int64_t n, int32_t *seqid, sann_wire_query_t *q, int64_t *consumed) {
+int sann_wire_decode_call(const uint8_t *buf, int64_t n, int32_t *seqid, sann_wire_query_t *q, int64_t *consumed) try {
   if (!buf || n < 0 || !q) return fail(ANNC_EINVAL, "NULL argument");
   R r(buf, n);
   if (int rc = read_message_begin(r, M_CALL, seqid)) return rc;
@@ -396,10 +399,10 @@ int sann_wire_decode_call(const uint8_t *buf, int64_t n, int32_t *seqid, sann_wi
   if (!seen) return fail(ANNC_EFORMAT, "getTweetCandidates_args: query is missing");
   if (consumed) *consumed = r.o;
   return ANNC_OK;
-}
+} ABI_CATCH
 
 int sann_wire_encode_reply(int32_t seqid, int32_t count, const int64_t *ids, const double *scores, uint8_t *buf, int64_t cap,
-                           int64_t *len) {
+                           int64_t *len) try {
   if (count < 0 || (count > 0 && (!ids || !scores))) return fail(ANNC_EINVAL, "bad candidate arrays");
   W w(buf, cap);
   write_message_begin(w, M_REPLY, seqid);
@@ -407,10 +410,10 @@ int sann_wire_encode_reply(int32_t seqid, int32_t count, const int64_t *ids, con
   write_candidates(w, count, ids, scores);
   w.stop();
   return w.finish(len);
-}
+} ABI_CATCH
 
 int sann_wire_decode_reply(const uint8_t *buf, int64_t n, int32_t *seqid, int32_t cap, int64_t *ids, double *scores, int32_t *count,
-                           int64_t *consumed) {
+                           int64_t *consumed) try {
   if (!buf || n < 0) return fail(ANNC_EINVAL, "NULL argument");
   R r(buf, n);
   if (int rc = read_message_begin(r, M_REPLY, seqid)) return rc;
@@ -427,10 +430,10 @@ int sann_wire_decode_reply(const uint8_t *buf, int64_t n, int32_t *seqid, int32_
   if (!seen) return fail(ANNC_EFORMAT, "getTweetCandidates_result: no success field (the server answered with an exception)");
   if (consumed) *consumed = r.o;
   return ANNC_OK;
-}
+} ABI_CATCH
 
 // ---- HNSW index files -----------------------------------------------------------------------------------------------
-int hnsw_codec_encode_internal_metadata(const hnsw_internal_metadata_t *m, uint8_t *buf, int64_t cap, int64_t *len) {
+int hnsw_codec_encode_internal_metadata(const hnsw_internal_metadata_t *m, uint8_t *buf, int64_t cap, int64_t *len) try {
   if (!m) return fail(ANNC_EINVAL, "metadata is NULL");
   W w(buf, cap);
   w.field(T_I32, 1); w.i32(m->max_level);
@@ -444,9 +447,9 @@ int hnsw_codec_encode_internal_metadata(const hnsw_internal_metadata_t *m, uint8
   w.field(T_I32, 5); w.i32(m->num_elements);
   w.stop();
   return w.finish(len);
-}
+} ABI_CATCH
 
-int hnsw_codec_decode_internal_metadata(const uint8_t *buf, int64_t n, hnsw_internal_metadata_t *m) {
+int hnsw_codec_decode_internal_metadata(const uint8_t *buf, int64_t n, hnsw_internal_metadata_t *m) try {
   if (!buf || n < 0 || !m) return fail(ANNC_EINVAL, "NULL argument");
   std::memset(m, 0, sizeof(*m));
   R r(buf, n);
@@ -465,18 +468,18 @@ int hnsw_codec_decode_internal_metadata(const uint8_t *buf, int64_t n, hnsw_inte
     }
     return 0;
   });
-}
+} ABI_CATCH
 
-int hnsw_codec_encode_index_metadata(int32_t dimension, int32_t metric, int32_t num_elements, uint8_t *buf, int64_t cap, int64_t *len) {
+int hnsw_codec_encode_index_metadata(int32_t dimension, int32_t metric, int32_t num_elements, uint8_t *buf, int64_t cap, int64_t *len) try {
   W w(buf, cap);
   w.field(T_I32, 1); w.i32(dimension);
   w.field(T_I32, 2); w.i32(metric);  // enums travel as i32
   w.field(T_I32, 3); w.i32(num_elements);
   w.stop();
   return w.finish(len);
-}
+} ABI_CATCH
 
-int hnsw_codec_decode_index_metadata(const uint8_t *buf, int64_t n, int32_t *dimension, int32_t *metric, int32_t *num_elements) {
+int hnsw_codec_decode_index_metadata(const uint8_t *buf, int64_t n, int32_t *dimension, int32_t *metric, int32_t *num_elements) try {
   if (!buf || n < 0) return fail(ANNC_EINVAL, "NULL argument");
   R r(buf, n);
   int32_t v[4] = {0, 0, 0, 0};
@@ -491,10 +494,10 @@ int hnsw_codec_decode_index_metadata(const uint8_t *buf, int64_t n, int32_t *dim
   if (metric) *metric = v[2];
   if (num_elements) *num_elements = v[3];
   return ANNC_OK;
-}
+} ABI_CATCH
 
 int hnsw_codec_encode_graph(int64_t n_entries, const int32_t *level, const int64_t *key, const int64_t *offsets,
-                            const int64_t *neighbours, uint8_t *buf, int64_t cap, int64_t *len) {
+                            const int64_t *neighbours, uint8_t *buf, int64_t cap, int64_t *len) try {
   if (n_entries < 0 || (n_entries > 0 && (!level || !key || !offsets))) return fail(ANNC_EINVAL, "bad graph arrays");
   W w(buf, cap);
   uint8_t k[8];
@@ -509,10 +512,10 @@ int hnsw_codec_encode_graph(int64_t n_entries, const int32_t *level, const int64
     w.stop();
   }
   return w.finish(len);
-}
+} ABI_CATCH
 
 int hnsw_codec_decode_graph(const uint8_t *buf, int64_t n, int64_t cap_entries, int64_t cap_neighbours, int32_t *level, int64_t *key,
-                            int64_t *offsets, int64_t *neighbours, int64_t *n_entries, int64_t *n_neighbours) {
+                            int64_t *offsets, int64_t *neighbours, int64_t *n_entries, int64_t *n_neighbours) try {
   if (!buf || n < 0) return fail(ANNC_EINVAL, "NULL argument");
   const bool store = level && key && offsets;
   R r(buf, n);
@@ -559,10 +562,10 @@ int hnsw_codec_decode_graph(const uint8_t *buf, int64_t n, int64_t cap_entries, 
   if (n_neighbours) *n_neighbours = nn;
   if (overflow) return fail(ANNC_ESPACE, "graph arrays too small: " + std::to_string(ne) + " entries, " + std::to_string(nn) + " neighbours");
   return ANNC_OK;
-}
+} ABI_CATCH
 
 int ann_wire_encode_neighbor_result(int32_t metric, int32_t count, const int64_t *ids, const float *distances, int32_t with_distance,
-                                    uint8_t *buf, int64_t cap, int64_t *len) {
+                                    uint8_t *buf, int64_t cap, int64_t *len) try {
   if (count < 0 || (count > 0 && (!ids || (with_distance && !distances)))) return fail(ANNC_EINVAL, "bad neighbour arrays");
   const int arm = metric == HNSW_METRIC_COSINE ? 1 : metric == HNSW_METRIC_L2 ? 2 : metric == HNSW_METRIC_INNER_PRODUCT ? 3 : 0;
   if (with_distance && !arm) return fail(ANNC_EINVAL, "unknown metric");
@@ -583,10 +586,10 @@ int ann_wire_encode_neighbor_result(int32_t metric, int32_t count, const int64_t
   }
   w.stop();
   return w.finish(len);
-}
+} ABI_CATCH
 
 int ann_wire_decode_neighbor_result(const uint8_t *buf, int64_t n, int32_t cap, int64_t *ids, double *distances, int32_t *arms,
-                                    int32_t *count, int64_t *consumed) {
+                                    int32_t *count, int64_t *consumed) try {
   if (!buf || n < 0) return fail(ANNC_EINVAL, "NULL argument");
   R r(buf, n);
   bool seen = false;
@@ -645,10 +648,10 @@ int ann_wire_decode_neighbor_result(const uint8_t *buf, int64_t n, int32_t cap, 
   if (consumed) *consumed = r.o;
   if (total > cap && (ids || distances || arms)) return fail(ANNC_ESPACE, "more neighbours than the output arrays hold");
   return ANNC_OK;
-}
+} ABI_CATCH
 
 // ---- directories ----------------------------------------------------------------------------------------------------
-int hnsw_index_save_directory(const hnsw_index_t *index, int32_t ef_construction, const char *dir) {
+int hnsw_index_save_directory(const hnsw_index_t *index, int32_t ef_construction, const char *dir) try {
   if (!index || !dir) return fail(ANNC_EINVAL, "NULL argument");
   int64_t n = 0, ne = 0, nn = 0, entry = -1;
   int32_t d = 0, metric = 0, max_m = 0, max_level = 0;
@@ -685,10 +688,10 @@ int hnsw_index_save_directory(const hnsw_index_t *index, int32_t ef_construction
   if (int rc = hnsw_codec_encode_index_metadata(d, metric, (int32_t)n, buf.data(), 64, &len)) return rc;
   if (int rc = write_file(root + "/hnsw_index_metadata", buf.data(), (size_t)len)) return rc;
   return write_file(root + "/_SUCCESS", nullptr, 0);  // HnswCommon.isValidHnswIndex wants hasSuccessFile
-}
+} ABI_CATCH
 
 int hnsw_index_load_directory(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
-                              const char *dir, hnsw_index_t **out) {
+                              const char *dir, hnsw_index_t **out) try {
   if (!dir || !out) return fail(ANNC_EINVAL, "NULL argument");
   const std::string root(dir), inner = root + "/hnsw_internal_index";
   std::vector<uint8_t> buf;
@@ -730,6 +733,6 @@ int hnsw_index_load_directory(int32_t device, int32_t metric, int64_t n, int32_t
                        off.data(), nb.data(), out))
     return fail(ANNC_EINVAL, std::string("hnsw_index_build: ") + hnsw_last_error());
   return ANNC_OK;
-}
+} ABI_CATCH
 
 }  // extern "C"

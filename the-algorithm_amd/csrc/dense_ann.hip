@@ -43,6 +43,8 @@
 
 #include "../../include/dense_ann.h"
 #include "sann_device.h"  // mix64
+#include "abi_guard.h"
+#define ABI_CATCH catch (...) { return abi_guard::caught(fail, DANN_ENOMEM, DANN_EINTERNAL); }
 
 namespace {
 
@@ -815,14 +817,14 @@ static int build_impl(int32_t device, int32_t metric, int64_t n, int32_t d, cons
                       dann_index_t **out);
 
 int dann_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
-                     dann_index_t **out) {
+                     dann_index_t **out) try {
   return build_impl(device, metric, n, d, vectors, ids, false, out);
-}
+} ABI_CATCH
 
 int dann_index_build_exact(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
-                           dann_index_t **out) {
+                           dann_index_t **out) try {
   return build_impl(device, metric, n, d, vectors, ids, true, out);
-}
+} ABI_CATCH
 
 static int build_impl(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids, bool exact,
                       dann_index_t **out) {
@@ -886,7 +888,7 @@ static int build_impl(int32_t device, int32_t metric, int64_t n, int32_t d, cons
   return DANN_OK;
 }
 
-int dann_index_build_synthetic(int32_t device, int32_t metric, int64_t n, int32_t d, uint64_t seed, dann_index_t **out) {
+int dann_index_build_synthetic(int32_t device, int32_t metric, int64_t n, int32_t d, uint64_t seed, dann_index_t **out) try {
   if (!out) return fail(DANN_EINVAL, "null argument");
   std::unique_ptr<dann_index> ix(new dann_index);
   int rc = alloc_index(ix.get(), device, metric, n, d);
@@ -900,9 +902,9 @@ int dann_index_build_synthetic(int32_t device, int32_t metric, int64_t n, int32_
   DTRY(hipDeviceSynchronize());
   *out = ix.release();
   return DANN_OK;
-}
+} ABI_CATCH
 
-int dann_index_get_vectors(const dann_index_t *ix, int64_t i0, int64_t n, float *out) {
+int dann_index_get_vectors(const dann_index_t *ix, int64_t i0, int64_t n, float *out) try {
   if (!ix || !out || i0 < 0 || n < 0 || i0 + n > ix->n) return fail(DANN_EINVAL, "range outside the index");
   if (n == 0) return DANN_OK;
   DTRY(hipSetDevice(ix->device));
@@ -914,18 +916,18 @@ int dann_index_get_vectors(const dann_index_t *ix, int64_t i0, int64_t n, float 
   DTRY(hipGetLastError());
   DTRY(hipMemcpy(out, tmp.p, (size_t)e * sizeof(float), hipMemcpyDeviceToHost));
   return DANN_OK;
-}
+} ABI_CATCH
 
-int dann_index_destroy(dann_index_t *ix) {
+int dann_index_destroy(dann_index_t *ix) try {
   delete ix;
   return DANN_OK;
-}
+} ABI_CATCH
 
 static int search_chunk(dann_index_t *ix, int32_t nq, const float *queries, int32_t k, float *out_dist, int64_t *out_ids,
                         int32_t *out_counts);
 
 int dann_search(dann_index_t *ix, int32_t nq, const float *queries, int32_t k, float *out_dist, int64_t *out_ids,
-                int32_t *out_counts) {
+                int32_t *out_counts) try {
   if (!ix || !queries || !out_dist || !out_ids || !out_counts) return fail(DANN_EINVAL, "null argument");
   if (nq < 1) return fail(DANN_EINVAL, "nq must be positive");
   if (k < 1 || k > MAX_K) return fail(DANN_EINVAL, "k must be in 1..1024");
@@ -943,7 +945,7 @@ int dann_search(dann_index_t *ix, int32_t nq, const float *queries, int32_t k, f
   ix->t_b = tb;
   ix->t_sel = ts;
   return DANN_OK;
-}
+} ABI_CATCH
 
 static int search_chunk(dann_index_t *ix, int32_t nq, const float *queries, int32_t k, float *out_dist, int64_t *out_ids,
                         int32_t *out_counts) {
@@ -1093,18 +1095,18 @@ static int search_chunk(dann_index_t *ix, int32_t nq, const float *queries, int3
   return DANN_OK;
 }
 
-int dann_last_rounds(const dann_index_t *ix, int32_t *rounds) {
+int dann_last_rounds(const dann_index_t *ix, int32_t *rounds) try {
   if (!ix || !rounds) return fail(DANN_EINVAL, "null argument");
   *rounds = ix->last_rounds;
   return DANN_OK;
-}
+} ABI_CATCH
 
-int dann_last_timing(const dann_index_t *ix, float *a_ms, float *b_ms, float *sel_ms) {
+int dann_last_timing(const dann_index_t *ix, float *a_ms, float *b_ms, float *sel_ms) try {
   if (!ix) return fail(DANN_EINVAL, "null index");
   if (a_ms) *a_ms = ix->t_a;
   if (b_ms) *b_ms = ix->t_b;
   if (sel_ms) *sel_ms = ix->t_sel;
   return DANN_OK;
-}
+} ABI_CATCH
 
 }  // extern "C"

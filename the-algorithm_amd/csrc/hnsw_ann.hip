@@ -36,6 +36,8 @@
 
 #include "../../include/hnsw_ann.h"
 #include "sann_device.h"  // mix64
+#include "abi_guard.h"
+#define ABI_CATCH catch (...) { return abi_guard::caught(fail, HNSW_ENOMEM, HNSW_EINTERNAL); }
 
 namespace {
 
@@ -974,7 +976,7 @@ const char *hnsw_last_error(void) { return g_err.c_str(); }
 int hnsw_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
                      int32_t max_m, int64_t entry_point, int32_t max_level, int64_t n_entries, const int32_t *entry_level,
                      const int64_t *entry_item, const int64_t *entry_offsets, const int64_t *entry_neighbours,
-                     hnsw_index_t **out) {
+                     hnsw_index_t **out) try {
   if (!out) return fail(HNSW_EINVAL, "out is NULL");
   if (n_entries < 0 || (n_entries > 0 && (!entry_level || !entry_item || !entry_offsets)))
     return fail(HNSW_EINVAL, "NULL graph arrays");
@@ -1008,25 +1010,25 @@ int hnsw_index_build(int32_t device, int32_t metric, int64_t n, int32_t d, const
   if (rc) return rc;
   *out = ix.release();
   return HNSW_OK;
-}
+} ABI_CATCH
 
 static int build_insert_impl(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
                              int32_t max_m, int32_t ef_construction, uint64_t seed, const int32_t *given_levels,
                              int32_t n_threads, hnsw_index_t **out);
 
 int hnsw_index_build_insert(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
-                            int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t n_threads, hnsw_index_t **out) {
+                            int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t n_threads, hnsw_index_t **out) try {
   return build_insert_impl(device, metric, n, d, vectors, ids, max_m, ef_construction, seed, nullptr, n_threads, out);
-}
+} ABI_CATCH
 
 int hnsw_index_build_insert_levels(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors,
                                    const int64_t *ids, int32_t max_m, int32_t ef_construction, const int32_t *levels,
-                                   int32_t n_threads, hnsw_index_t **out) {
+                                   int32_t n_threads, hnsw_index_t **out) try {
   if (!levels && n > 0) return fail(HNSW_EINVAL, "levels is NULL");
   for (int64_t i = 0; i < n; ++i)
     if (levels[i] < 0 || levels[i] > 60) return fail(HNSW_EINVAL, "a level is outside 0..60");
   return build_insert_impl(device, metric, n, d, vectors, ids, max_m, ef_construction, 0, levels, n_threads, out);
-}
+} ABI_CATCH
 
 static int build_insert_impl(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
                              int32_t max_m, int32_t ef_construction, uint64_t seed, const int32_t *given_levels,
@@ -1090,7 +1092,7 @@ static int build_insert_impl(int32_t device, int32_t metric, int64_t n, int32_t 
 // in batches on the GPU (see hnsw_link_kernel).  batch = items per round (0 = 4096; a round never holds more than an
 // eighth of the graph it searches, so early rounds are small).
 int hnsw_index_build_insert_gpu(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
-                                int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t batch, hnsw_index_t **out) {
+                                int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t batch, hnsw_index_t **out) try {
   if (!out) return fail(HNSW_EINVAL, "out is NULL");
   if (ef_construction < 1 || ef_construction > LINK_CAND) return fail(HNSW_EINVAL, "ef_construction must be in 1..256");
   if (batch < 0) return fail(HNSW_EINVAL, "batch must not be negative");
@@ -1253,10 +1255,10 @@ int hnsw_index_build_insert_gpu(int32_t device, int32_t metric, int64_t n, int32
   }
   *out = ix.release();
   return HNSW_OK;
-}
+} ABI_CATCH
 
 int hnsw_index_graph_size(const hnsw_index_t *ix, int64_t *n_entries, int64_t *n_neighbours, int64_t *entry_point,
-                          int32_t *max_level) {
+                          int32_t *max_level) try {
   if (!ix) return fail(HNSW_EINVAL, "NULL index");
   int64_t ne = 0, nn = 0;
   for (int64_t i = 0; i < ix->n; ++i)
@@ -1275,10 +1277,10 @@ int hnsw_index_graph_size(const hnsw_index_t *ix, int64_t *n_entries, int64_t *n
   if (entry_point) *entry_point = ix->entry;
   if (max_level) *max_level = ix->max_level;
   return HNSW_OK;
-}
+} ABI_CATCH
 
 int hnsw_index_graph(const hnsw_index_t *ix, int32_t *entry_level, int64_t *entry_item, int64_t *entry_offsets,
-                     int64_t *entry_neighbours) {
+                     int64_t *entry_neighbours) try {
   if (!ix || !entry_level || !entry_item || !entry_offsets) return fail(HNSW_EINVAL, "NULL argument");
   int64_t e = 0, pos = 0;
   entry_offsets[0] = 0;
@@ -1297,9 +1299,9 @@ int hnsw_index_graph(const hnsw_index_t *ix, int32_t *entry_level, int64_t *entr
     for (size_t s = 0; s < ix->upper[l].size(); ++s)
       if (l < ix->has_upper[s].size() && ix->has_upper[s][l]) emit((int)l + 1, slot_item[s], ix->upper[l][s]);
   return HNSW_OK;
-}
+} ABI_CATCH
 
-int hnsw_index_get_vectors(const hnsw_index_t *ix, int64_t i0, int64_t n, float *out) {
+int hnsw_index_get_vectors(const hnsw_index_t *ix, int64_t i0, int64_t n, float *out) try {
   if (!ix || !out || i0 < 0 || n < 0 || i0 + n > ix->n) return fail(HNSW_EINVAL, "range outside the index");
   if (n == 0) return HNSW_OK;
   HTRY(hipSetDevice(ix->device));
@@ -1311,18 +1313,18 @@ int hnsw_index_get_vectors(const hnsw_index_t *ix, int64_t i0, int64_t n, float 
   HTRY(hipGetLastError());
   HTRY(hipMemcpy(out, tmp.p, (size_t)e * 4, hipMemcpyDeviceToHost));
   return HNSW_OK;
-}
+} ABI_CATCH
 
-int hnsw_index_info(const hnsw_index_t *ix, int64_t *n, int32_t *d, int32_t *metric, int32_t *max_m) {
+int hnsw_index_info(const hnsw_index_t *ix, int64_t *n, int32_t *d, int32_t *metric, int32_t *max_m) try {
   if (!ix) return fail(HNSW_EINVAL, "NULL index");
   if (n) *n = ix->n;
   if (d) *d = ix->d;
   if (metric) *metric = ix->metric;
   if (max_m) *max_m = ix->m;
   return HNSW_OK;
-}
+} ABI_CATCH
 
-int hnsw_index_get_ids(const hnsw_index_t *ix, int64_t *out) {
+int hnsw_index_get_ids(const hnsw_index_t *ix, int64_t *out) try {
   if (!ix || (!out && ix->n > 0)) return fail(HNSW_EINVAL, "NULL argument");
   if (ix->n == 0) return HNSW_OK;
   if (!ix->has_ids) {
@@ -1332,15 +1334,15 @@ int hnsw_index_get_ids(const hnsw_index_t *ix, int64_t *out) {
   HTRY(hipSetDevice(ix->device));
   HTRY(hipMemcpy(out, ix->ids.p, (size_t)ix->n * 8, hipMemcpyDeviceToHost));
   return HNSW_OK;
-}
+} ABI_CATCH
 
-int hnsw_index_destroy(hnsw_index_t *ix) {
+int hnsw_index_destroy(hnsw_index_t *ix) try {
   delete ix;
   return HNSW_OK;
-}
+} ABI_CATCH
 
 int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, int32_t ef, float *out_dist, int64_t *out_ids,
-                int32_t *out_counts) {
+                int32_t *out_counts) try {
   if (!ix || !queries || !out_dist || !out_ids || !out_counts) return fail(HNSW_EINVAL, "NULL argument");
   if (nq < 1) return fail(HNSW_EINVAL, "nq must be positive");
   if (k < 1 || ef < 1) return fail(HNSW_EINVAL, "k and ef must be positive");
@@ -1503,16 +1505,16 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   }
   (void)hipEventElapsedTime(&ix->last_ms, ix->ev[0], ix->ev[1]);
   return HNSW_OK;
-}
+} ABI_CATCH
 
 int hnsw_last_stats(const hnsw_index_t *ix, int64_t *distance_evals, int64_t *expansions, int32_t *spilled_queries,
-                    float *kernel_ms) {
+                    float *kernel_ms) try {
   if (!ix) return fail(HNSW_EINVAL, "NULL index");
   if (distance_evals) *distance_evals = ix->last_dist;
   if (expansions) *expansions = ix->last_exp;
   if (spilled_queries) *spilled_queries = ix->last_spilled;
   if (kernel_ms) *kernel_ms = ix->last_ms;
   return HNSW_OK;
-}
+} ABI_CATCH
 
 }  // extern "C"

@@ -17,6 +17,8 @@
 
 #include "../../include/representation_scorer.h"
 #include "sann_math.h"
+#include "abi_guard.h"
+#define ABI_CATCH catch (...) { return abi_guard::caught(rsx_fail, RSX_ENOMEM, RSX_EINTERNAL); }
 
 namespace {
 
@@ -215,7 +217,7 @@ const char *rsx_last_error(void) { return g_rsx_err.c_str(); }
 
 int rsx_pair_scores_device(int32_t device, void *hip_stream, int32_t algorithm, int32_t n_pairs, const void *d_a_offsets,
                            const void *d_a_cluster_ids, const void *d_a_scores, const void *d_b_offsets,
-                           const void *d_b_cluster_ids, const void *d_b_scores, void *d_out_scores) {
+                           const void *d_b_cluster_ids, const void *d_b_scores, void *d_out_scores) try {
   if (n_pairs < 0) return rsx_fail(RSX_EINVAL, "n_pairs < 0");
   if (algorithm < 1 || algorithm > 7) return rsx_fail(RSX_EINVAL, "unknown pair scoring algorithm");  // IllegalArgumentException in ScoreFacadeStore
   if (n_pairs == 0) return RSX_OK;
@@ -229,11 +231,11 @@ int rsx_pair_scores_device(int32_t device, void *hip_stream, int32_t algorithm, 
   e = hipGetLastError();
   if (e != hipSuccess) return rsx_fail(RSX_EDEVICE, hipGetErrorString(e));
   return RSX_OK;
-}
+} ABI_CATCH
 
 int rsx_pair_scores(int32_t device, int32_t algorithm, int32_t n_pairs, const int64_t *a_offsets,
                     const int32_t *a_cluster_ids, const double *a_scores, const int64_t *b_offsets,
-                    const int32_t *b_cluster_ids, const double *b_scores, int32_t validate, double *out_scores) {
+                    const int32_t *b_cluster_ids, const double *b_scores, int32_t validate, double *out_scores) try {
   if (n_pairs < 0) return rsx_fail(RSX_EINVAL, "n_pairs < 0");
   if (algorithm < 1 || algorithm > 7) return rsx_fail(RSX_EINVAL, "unknown pair scoring algorithm");
   if (n_pairs == 0) return RSX_OK;
@@ -274,10 +276,10 @@ int rsx_pair_scores(int32_t device, int32_t algorithm, int32_t n_pairs, const in
   e = hipMemcpy(out_scores, dout.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost);
   if (e != hipSuccess) return rsx_fail(RSX_EDEVICE, hipGetErrorString(e));
   return RSX_OK;
-}
+} ABI_CATCH
 
 int rsx_store_build(int32_t device, int64_t n, const int64_t *ids, const int64_t *offsets, const int32_t *cluster_ids,
-                    const double *scores, rsx_store_t **out) {
+                    const double *scores, rsx_store_t **out) try {
   if (!out || n < 0 || (n > 0 && (!ids || !offsets))) return rsx_fail(RSX_EINVAL, "NULL argument");
   if (n >= 0x7fffffff) return rsx_fail(RSX_EINVAL, "too many embeddings");
   const int64_t total = n ? offsets[n] : 0;
@@ -301,15 +303,15 @@ int rsx_store_build(int32_t device, int64_t n, const int64_t *ids, const int64_t
   RSX_TRY(st->sc.put(scores, (size_t)total * 8));
   *out = st.release();
   return RSX_OK;
-}
+} ABI_CATCH
 
-int rsx_store_destroy(rsx_store_t *store) {
+int rsx_store_destroy(rsx_store_t *store) try {
   delete store;
   return RSX_OK;
-}
+} ABI_CATCH
 
 int rsx_store_pair_scores(const rsx_store_t *a, const rsx_store_t *b, int32_t algorithm, int32_t n_pairs,
-                          const int64_t *a_ids, const int64_t *b_ids, double *out_scores, uint8_t *out_present) {
+                          const int64_t *a_ids, const int64_t *b_ids, double *out_scores, uint8_t *out_present) try {
   if (!a || !b || n_pairs < 0) return rsx_fail(RSX_EINVAL, "NULL store or n_pairs < 0");
   if (algorithm < 1 || algorithm > 7) return rsx_fail(RSX_EINVAL, "unknown pair scoring algorithm");
   if (a->device != b->device) return rsx_fail(RSX_EINVAL, "stores live on different devices");
@@ -321,10 +323,10 @@ int rsx_store_pair_scores(const rsx_store_t *a, const rsx_store_t *b, int32_t al
     rb[(size_t)i] = b->row_of(b_ids[i]);
   }
   return rows_scores(a, b, algorithm, n_pairs, ra, rb, out_scores, out_present);
-}
+} ABI_CATCH
 
 int rsx_store_list_scores(const rsx_store_t *targets, const rsx_store_t *candidates, int32_t algorithm, int64_t target_id,
-                          int32_t n_candidates, const int64_t *candidate_ids, double *out_scores, uint8_t *out_present) {
+                          int32_t n_candidates, const int64_t *candidate_ids, double *out_scores, uint8_t *out_present) try {
   if (!targets || !candidates || n_candidates < 0) return rsx_fail(RSX_EINVAL, "NULL store or n_candidates < 0");
   if (algorithm < 1 || algorithm > 7) return rsx_fail(RSX_EINVAL, "unknown pair scoring algorithm");
   if (targets->device != candidates->device) return rsx_fail(RSX_EINVAL, "stores live on different devices");
@@ -333,13 +335,13 @@ int rsx_store_list_scores(const rsx_store_t *targets, const rsx_store_t *candida
   std::vector<int32_t> ra((size_t)n_candidates, targets->row_of(target_id)), rb((size_t)n_candidates);
   for (int32_t i = 0; i < n_candidates; i++) rb[(size_t)i] = candidates->row_of(candidate_ids[i]);
   return rows_scores(targets, candidates, algorithm, n_candidates, ra, rb, out_scores, out_present);
-}
+} ABI_CATCH
 
 int rsx_store_group_features(const rsx_store_t *candidates, int32_t algorithm, int32_t n_candidates,
                              const int64_t *candidate_ids, int32_t n_maps, const rsx_store_t *const *map_stores,
                              const int64_t *map_id_offsets, const int64_t *map_ids, int32_t n_groups,
                              const int32_t *group_map, const int64_t *group_offsets, const int64_t *group_member_ids,
-                             double *out_avg, double *out_max, int32_t *out_count) {
+                             double *out_avg, double *out_max, int32_t *out_count) try {
   if (!candidates || n_candidates < 0 || n_groups < 0) return rsx_fail(RSX_EINVAL, "NULL store or negative size");
   if (algorithm < 1 || algorithm > 7) return rsx_fail(RSX_EINVAL, "unknown pair scoring algorithm");
   if (n_maps < 1 || n_maps > RSX_MAX_MAPS) return rsx_fail(RSX_EINVAL, "n_maps must be in 1..4");
@@ -402,6 +404,6 @@ int rsx_store_group_features(const rsx_store_t *candidates, int32_t algorithm, i
   RSX_TRY(hipMemcpy(out_max, dmax.p, nout * 8, hipMemcpyDeviceToHost));
   RSX_TRY(hipMemcpy(out_count, dcnt.p, nout * 4, hipMemcpyDeviceToHost));
   return RSX_OK;
-}
+} ABI_CATCH
 
 }  // extern "C"

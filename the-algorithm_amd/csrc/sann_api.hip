@@ -23,6 +23,7 @@
 #include "../../include/simclusters_ann.h"
 #include "sann_host.h"
 #include "sann_kernels.h"
+#include "abi_guard.h"
 
 using namespace sann;
 
@@ -36,16 +37,19 @@ int fail(int code, const std::string &msg) {
 using sann_host::DevBuf;
 using sann_host::fail;
 using sann_host::g_err;
+#define ABI_CATCH catch (...) { return abi_guard::caught(sann_host::fail, SANN_ENOMEM, SANN_EINTERNAL); }
 
 namespace {
 
 // Batches kept in flight -- sann_batch_run_after, and the pooled sann_get_tweet_candidates from several threads --
 // run on several HIP streams.  The runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and
 // two streams that land on one queue execute in order: the overlap is then lost without any error (round 1 measured
-// 0.58 ms instead of 0.36 ms per batch).  The variable is read when the HIP runtime initialises, so the library sets
-// it (if the process has not) when it is loaded, and says so once on stderr if it finds the runtime up with fewer.
+// 0.58 ms instead of 0.36 ms per batch).  The variable is read when the HIP runtime initialises, i.e. it belongs to the
+// PROCESS: the launcher / JVM shim exports GPU_MAX_HW_QUEUES=8 before the process starts (INTEGRATION.md section 2;
+// bench.py and the Python mirror do it before they load anything).  The library itself never touches the environment
+// (setenv is not thread-safe against a running JVM's getenv, and it would change HIP for every other user of the
+// process); it only reports, once, when it finds fewer queues than its streams want.
 std::string g_advice;
-__attribute__((constructor)) void sann_set_hw_queue_default() { setenv("GPU_MAX_HW_QUEUES", "8", 0 /* keep the caller's choice */); }
 void check_hw_queues_once() {
   static std::once_flag once;
   std::call_once(once, [] {
@@ -254,6 +258,7 @@ struct sann_batch {
   // caller-bound output buffers (NULL = the batch's own)
   void *bound_ids = nullptr, *bound_scores = nullptr, *bound_counts = nullptr, *bound_map_sizes = nullptr;
   int32_t bound_chunk_q = 0;  // 0 = outputs are one chunk
+  int32_t bound_nq = 0, bound_stride = 0;  // the batch's shape when the outputs were bound = what the caller sized them for
   hipEvent_t ev_unit_done = nullptr;  // sann_batch_run_after: recorded behind the unit kernel(s)
   hipEvent_t last_unit_done = nullptr;
   hipEvent_t ev_all_done = nullptr;  // sann_batch_run_after: recorded behind the merge kernel
@@ -461,20 +466,20 @@ static int index_build_impl(const sann_index_options_t *opts, int32_t n_lists, c
 }
 
 int sann_index_build(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
-                     const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores, sann_index_t **out) {
+                     const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores, sann_index_t **out) try {
   return index_build_impl(opts, n_lists, cluster_ids, list_offsets, tweet_ids, scores, nullptr, out);
-}
+} ABI_CATCH
 
 int sann_index_build_with_norms(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
                                 const int64_t *list_offsets, const int64_t *tweet_ids, const double *scores,
-                                const double *tweet_norms, sann_index_t **out) {
+                                const double *tweet_norms, sann_index_t **out) try {
   if (!tweet_norms && n_lists > 0 && list_offsets && list_offsets[n_lists] > list_offsets[0])
     return fail(SANN_EINVAL, "tweet_norms is NULL");
   static const double none = 0.0;
   return index_build_impl(opts, n_lists, cluster_ids, list_offsets, tweet_ids, scores, tweet_norms ? tweet_norms : &none, out);
-}
+} ABI_CATCH
 
-int sann_index_info(const sann_index_t *ix, sann_index_info_t *info) {
+int sann_index_info(const sann_index_t *ix, sann_index_info_t *info) try {
   if (!ix || !info) return fail(SANN_EINVAL, "NULL argument");
   info->n_clusters = (int64_t)ix->cluster_ids.size();
   info->n_postings = ix->n_postings;
@@ -485,10 +490,10 @@ int sann_index_info(const sann_index_t *ix, sann_index_info_t *info) {
   info->n_shards = ix->n_shards;
   info->max_list_len = ix->max_list_len;
   return SANN_OK;
-}
+} ABI_CATCH
 
 int sann_index_get_list(const sann_index_t *ix, int32_t cluster_id, int64_t cap, int64_t *tweet_ids, double *scores,
-                        int32_t *ranks, int64_t *n) {
+                        int32_t *ranks, int64_t *n) try {
   if (!ix || !n) return fail(SANN_EINVAL, "NULL argument");
   *n = 0;
   int row = ix->row_of(cluster_id);
@@ -513,14 +518,14 @@ int sann_index_get_list(const sann_index_t *ix, int32_t cluster_id, int64_t cap,
     if (ranks) ranks[i] = (int32_t)r[o];
   }
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_index_destroy(sann_index_t *ix) {
+int sann_index_destroy(sann_index_t *ix) try {
   if (!ix) return SANN_OK;
   (void)hipSetDevice(ix->device);
   delete ix;
   return SANN_OK;
-}
+} ABI_CATCH
 
 }  // extern "C"
 
@@ -542,11 +547,14 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
   if (nq < 0) return fail(SANN_EINVAL, "nq < 0");
   if (nq > 0 && (!emb_offsets || !configs)) return fail(SANN_EINVAL, "emb_offsets/configs are NULL");
   if (n_configs != 1 && n_configs != nq) return fail(SANN_EINVAL, "n_configs must be 1 or nq");
-  if ((scan_offsets == nullptr) != (scan_cluster_ids == nullptr) && nq > 0 && scan_offsets &&
-      scan_offsets[nq] != scan_offsets[0])
+  // the explicit scan keys come as a CSR pair: one without the other is a caller bug (silently falling back to the
+  // default truncation would answer a different question with SANN_OK); an all-empty region may leave the ids NULL
+  if (nq > 0 && (scan_offsets == nullptr) != (scan_cluster_ids == nullptr) &&
+      !(scan_offsets && scan_offsets[nq] == scan_offsets[0]))
     return fail(SANN_EINVAL, "scan_offsets and scan_cluster_ids must be given together");
   if ((int64_t)nq * ix->P > (int64_t)INT32_MAX / 2) return fail(SANN_ELIMIT, "nq * n_partitions too large");
-  const bool has_scan = scan_offsets != nullptr && scan_cluster_ids != nullptr;
+  // (offsets with an all-empty region and no ids: explicit keys, none of them -- every query scans nothing)
+  const bool has_scan = scan_offsets != nullptr && (scan_cluster_ids != nullptr || nq == 0 || scan_offsets[nq] == scan_offsets[0]);
   const bool has_sources = has_source_tweet != nullptr && source_tweet_ids != nullptr;
 
   // ---- O(nq) pass over the arguments: validation, the scan regions' upper bounds, k, M ----------------------------
@@ -626,6 +634,13 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
   }
   apriori_mean /= (double)ix->P * (double)ix->n_shards;
 
+  // caller-bound output buffers were sized for the batch's shape at bind time (nq rows of `stride` entries, and for
+  // the chunked form ceil(nq / queries_per_chunk) chunks): a reset must fit inside it, or the merge kernels would
+  // write past the caller's buffers
+  if (b->bound_ids && (nq > b->bound_nq || kmax > b->bound_stride))
+    return fail(SANN_EINVAL, "the batch's outputs are bound to caller-owned buffers sized for " + std::to_string(b->bound_nq) +
+                                 " queries x " + std::to_string(b->bound_stride) + " results; this reset needs " + std::to_string(nq) +
+                                 " x " + std::to_string(kmax) + " (unbind or bind larger buffers first)");
   b->nq = nq;
   b->now_ms = now_ms;
   b->n_units = nq * ix->P;
@@ -845,7 +860,7 @@ extern "C" {
 int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t nq, const int64_t *emb_offsets,
                       const int32_t *emb_cluster_ids, const double *emb_scores, const int64_t *source_tweet_ids,
                       const uint8_t *has_source_tweet, const sann_config_t *configs, int32_t n_configs,
-                      const int64_t *scan_offsets, const int32_t *scan_cluster_ids, sann_batch_t **out) {
+                      const int64_t *scan_offsets, const int32_t *scan_cluster_ids, sann_batch_t **out) try {
   if (!out) return fail(SANN_EINVAL, "out is NULL");
   *out = nullptr;
   if (!ix) return fail(SANN_EINVAL, "index is NULL");
@@ -867,16 +882,16 @@ int sann_batch_create(sann_index_t *ix, int32_t variant, int64_t now_ms, int32_t
   }
   *out = b;
   return SANN_OK;
-}
+} ABI_CATCH
 
 int sann_batch_reset(sann_batch_t *b, void *hip_stream, int64_t now_ms, int32_t nq, const int64_t *emb_offsets,
                      const int32_t *emb_cluster_ids, const double *emb_scores, const int64_t *source_tweet_ids,
                      const uint8_t *has_source_tweet, const sann_config_t *configs, int32_t n_configs,
-                     const int64_t *scan_offsets, const int32_t *scan_cluster_ids) {
+                     const int64_t *scan_offsets, const int32_t *scan_cluster_ids) try {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
   return batch_reset(b, (hipStream_t)hip_stream, now_ms, nq, emb_offsets, emb_cluster_ids, emb_scores, source_tweet_ids,
                      has_source_tweet, configs, n_configs, scan_offsets, scan_cluster_ids);
-}
+} ABI_CATCH
 
 }  // extern "C"
 
@@ -910,6 +925,47 @@ int ensure_unit_bounds(sann_batch *b, const std::vector<int32_t> &queries) {
     for (int p = 0; p < P; p++)
       b->unit_bound[(size_t)q * P + p] = (uint32_t)std::min<uint64_t>(hq.unit_bound[(size_t)p], 0x7fffffffu);
   }
+  return SANN_OK;
+}
+
+// status[0] / status[1] as the kernels left them: counts of list entries, bounded by the batch's shape
+int check_status_counts(int64_t n_over, int64_t n_inexact, int64_t n_units, int64_t nq) {
+  if (n_over < 0 || n_over > n_units || n_inexact < 0 || n_inexact > nq)
+    return fail(SANN_EINTERNAL, "device status block out of range: overflow units " + std::to_string(n_over) + " of " +
+                                    std::to_string(n_units) + ", inexact queries " + std::to_string(n_inexact) + " of " +
+                                    std::to_string(nq));
+  return SANN_OK;
+}
+
+// What the slow tail re-runs, from the lists the kernels left: `over` = units the fast path could not hold, `inexact` =
+// queries whose top-k the merge could not prove.  An inexact query is re-run whole, an overflowed unit alone; `queries`
+// = every query that needs its merge repeated.  Pure host arithmetic on DEVICE-WRITTEN values: every id is range-checked
+// (a corrupted entry is SANN_EINTERNAL, not an out-of-bounds write), duplicates are tolerated.
+int plan_slow_tail(int nq, int P, const std::vector<int32_t> &over, const std::vector<int32_t> &inexact,
+                   std::vector<int32_t> &units, std::vector<int32_t> &queries) {
+  units.clear();
+  queries.clear();
+  if (nq < 0 || P < 1) return fail(SANN_EINTERNAL, "slow tail: bad batch shape");
+  const int64_t n_units = (int64_t)nq * P;
+  std::vector<uint8_t> q_mark((size_t)nq, 0), q_full((size_t)nq, 0);
+  for (int32_t q : inexact) {
+    if (q < 0 || q >= nq) return fail(SANN_EINTERNAL, "slow tail: inexact query id " + std::to_string(q) + " outside the batch");
+    q_mark[(size_t)q] = 1;
+    q_full[(size_t)q] = 1;
+  }
+  for (int32_t u : over) {
+    if (u < 0 || (int64_t)u >= n_units) return fail(SANN_EINTERNAL, "slow tail: overflow unit id " + std::to_string(u) + " outside the batch");
+    const int q = u / P;
+    q_mark[(size_t)q] = 1;
+    if (!q_full[(size_t)q]) units.push_back(u);
+  }
+  for (int q = 0; q < nq; q++) {
+    if (q_full[(size_t)q])
+      for (int p = 0; p < P; p++) units.push_back(q * P + p);
+    if (q_mark[(size_t)q]) queries.push_back(q);
+  }
+  std::sort(units.begin(), units.end());
+  units.erase(std::unique(units.begin(), units.end()), units.end());
   return SANN_OK;
 }
 
@@ -1008,13 +1064,15 @@ static int batch_run(sann_batch_t *b, void *hip_stream, bool chained, sann_batch
   return SANN_OK;
 }
 
-int sann_batch_run(sann_batch_t *b, void *hip_stream) { return batch_run(b, hip_stream, false, nullptr, false); }
+int sann_batch_run(sann_batch_t *b, void *hip_stream) try {
+  return batch_run(b, hip_stream, false, nullptr, false);
+} ABI_CATCH
 
-int sann_batch_run_after(sann_batch_t *b, void *hip_stream, sann_batch_t *after, int32_t after_merge) {
+int sann_batch_run_after(sann_batch_t *b, void *hip_stream, sann_batch_t *after, int32_t after_merge) try {
   return batch_run(b, hip_stream, true, after, after_merge != 0);
-}
+} ABI_CATCH
 
-int sann_batch_finish(sann_batch_t *b, void *hip_stream) {
+int sann_batch_finish(sann_batch_t *b, void *hip_stream) try {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
   if (!b->ran) return fail(SANN_EINVAL, "sann_batch_run was not called");
   hipStream_t st = (hipStream_t)hip_stream;
@@ -1065,27 +1123,19 @@ int sann_batch_finish(sann_batch_t *b, void *hip_stream) {
   if (!b->use_fast) return fail(SANN_EINTERNAL, "general path reported overflow/inexact units");
 
   // ---- slow tail: re-run on the general path whatever the fast path could not settle ---------
+  // The two counts and the two lists were written by kernels: they are range-checked before they size or index
+  // anything on the host (plan_slow_tail), so a corrupted status block is an error code, never a C++ exception or a
+  // wild write inside the caller's process.
   const int P = b->ix->P;
+  if (int rc0 = check_status_counts(n_over, n_inexact, b->n_units, b->nq)) return rc0;
   std::vector<int32_t> over((size_t)n_over), inexact((size_t)n_inexact);
   if (n_over) HIP_TRY(hipMemcpy(over.data(), b->overflow_units.p, (size_t)n_over * 4, hipMemcpyDeviceToHost));
   if (n_inexact)
     HIP_TRY(hipMemcpy(inexact.data(), b->status.as<int32_t>() + 2, (size_t)n_inexact * 4, hipMemcpyDeviceToHost));
-  std::vector<uint8_t> q_mark((size_t)b->nq, 0), q_full((size_t)b->nq, 0);
-  for (int32_t q : inexact) { q_mark[(size_t)q] = 1; q_full[(size_t)q] = 1; }
   std::vector<int32_t> units, queries;
-  for (int32_t u : over) {
-    int q = u / P;
-    q_mark[(size_t)q] = 1;
-    if (!q_full[(size_t)q]) units.push_back(u);
-  }
-  for (int q = 0; q < b->nq; q++) {
-    if (q_full[(size_t)q])
-      for (int p = 0; p < P; p++) units.push_back(q * P + p);
-    if (q_mark[(size_t)q]) queries.push_back(q);
-  }
-  std::sort(units.begin(), units.end());
-  units.erase(std::unique(units.begin(), units.end()), units.end());
-  int rc = ensure_unit_bounds(b, queries);
+  int rc = plan_slow_tail(b->nq, P, over, inexact, units, queries);
+  if (rc != SANN_OK) return rc;
+  rc = ensure_unit_bounds(b, queries);
   if (rc != SANN_OK) return rc;
   rc = run_general(b, units, st);
   if (rc != SANN_OK) return rc;
@@ -1100,7 +1150,7 @@ int sann_batch_finish(sann_batch_t *b, void *hip_stream) {
   if (b->h_status[0] != 0 || b->h_status[1] != 0)
     return fail(SANN_EINTERNAL, "general path could not settle the flagged units");
   return SANN_OK;
-}
+} ABI_CATCH
 
 static int results_impl(sann_batch_t *b, hipStream_t st, int64_t *out_ids, double *out_scores, int32_t out_stride,
                         int32_t *out_counts, int32_t *out_map_sizes) {
@@ -1127,13 +1177,13 @@ static int results_impl(sann_batch_t *b, hipStream_t st, int64_t *out_ids, doubl
 }
 
 int sann_batch_results(sann_batch_t *b, int64_t *out_ids, double *out_scores, int32_t out_stride, int32_t *out_counts,
-                       int32_t *out_map_sizes) {
+                       int32_t *out_map_sizes) try {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
   return results_impl(b, b->own_stream, out_ids, out_scores, out_stride, out_counts, out_map_sizes);
-}
+} ABI_CATCH
 
 int sann_batch_device_results(sann_batch_t *b, void **d_ids, void **d_scores, void **d_counts, void **d_map_sizes,
-                              int32_t *stride) {
+                              int32_t *stride) try {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
   if (b->bound_chunk_q > 0) return fail(SANN_EINVAL, "outputs are bound to caller-owned chunked buffers");
   BatchView bv = b->view();
@@ -1143,9 +1193,9 @@ int sann_batch_device_results(sann_batch_t *b, void **d_ids, void **d_scores, vo
   if (d_map_sizes) *d_map_sizes = bv.out_map_sizes;
   if (stride) *stride = b->stride;
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_batch_bind_outputs(sann_batch_t *b, void *d_ids, void *d_scores, void *d_counts, void *d_map_sizes) {
+int sann_batch_bind_outputs(sann_batch_t *b, void *d_ids, void *d_scores, void *d_counts, void *d_map_sizes) try {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
   bool all = d_ids && d_scores && d_counts && d_map_sizes, none = !d_ids && !d_scores && !d_counts && !d_map_sizes;
   if (!all && !none) return fail(SANN_EINVAL, "bind all four output buffers or none");
@@ -1155,11 +1205,13 @@ int sann_batch_bind_outputs(sann_batch_t *b, void *d_ids, void *d_scores, void *
   b->bound_map_sizes = d_map_sizes;
   b->bound_chunk_q = 0;
   b->bound_chunk_pitch = 0;
+  b->bound_nq = b->nq;
+  b->bound_stride = b->stride;
   return SANN_OK;
-}
+} ABI_CATCH
 
 int sann_batch_bind_outputs_chunked(sann_batch_t *b, void *d_ids, void *d_scores, void *d_counts, void *d_map_sizes,
-                                    int32_t queries_per_chunk, int64_t chunk_pitch_bytes) {
+                                    int32_t queries_per_chunk, int64_t chunk_pitch_bytes) try {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
   if (!d_ids || !d_scores || !d_counts || !d_map_sizes) return fail(SANN_EINVAL, "NULL output buffer");
   if (queries_per_chunk < 1 || chunk_pitch_bytes < 0 || (chunk_pitch_bytes & 7))
@@ -1170,22 +1222,24 @@ int sann_batch_bind_outputs_chunked(sann_batch_t *b, void *d_ids, void *d_scores
   b->bound_map_sizes = d_map_sizes;
   b->bound_chunk_q = queries_per_chunk;
   b->bound_chunk_pitch = chunk_pitch_bytes;
+  b->bound_nq = b->nq;
+  b->bound_stride = b->stride;
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_batch_device_k(sann_batch_t *b, void **d_k) {
+int sann_batch_device_k(sann_batch_t *b, void **d_k) try {
   if (!b || !d_k) return fail(SANN_EINVAL, "NULL argument");
   *d_k = b->d_k.p;
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_batch_stats(sann_batch_t *b, sann_batch_stats_t *stats) {
+int sann_batch_stats(sann_batch_t *b, sann_batch_stats_t *stats) try {
   if (!b || !stats) return fail(SANN_EINVAL, "NULL argument");
   *stats = b->stats;
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_batch_set_profiling(sann_batch_t *b, int32_t enable) {
+int sann_batch_set_profiling(sann_batch_t *b, int32_t enable) try {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
   HIP_TRY(hipSetDevice(b->ix->device));
   if (enable)
@@ -1197,9 +1251,9 @@ int sann_batch_set_profiling(sann_batch_t *b, int32_t enable) {
   b->timed_runs = 0;
   b->ev_pending = false;
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_batch_kernel_times(sann_batch_t *b, double *unit_ms_total, double *merge_ms_total, int32_t *n_runs) {
+int sann_batch_kernel_times(sann_batch_t *b, double *unit_ms_total, double *merge_ms_total, int32_t *n_runs) try {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
   // unit_ms_total covers the unit kernel alone; the descriptor kernel is reported by
   // sann_batch_desc_time
@@ -1207,9 +1261,9 @@ int sann_batch_kernel_times(sann_batch_t *b, double *unit_ms_total, double *merg
   if (merge_ms_total) *merge_ms_total = b->merge_ms_total;
   if (n_runs) *n_runs = b->timed_runs;
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_debug_phase_cycles(sann_batch_t *b, int32_t enable, double *avg16) {
+int sann_debug_phase_cycles(sann_batch_t *b, int32_t enable, double *avg16) try {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
   HIP_TRY(hipSetDevice(b->ix->device));
   if (enable) {
@@ -1265,10 +1319,10 @@ int sann_debug_phase_cycles(sann_batch_t *b, int32_t enable, double *avg16) {
   }
   HIP_TRY(b->prof.alloc(0));
   return SANN_OK;
-}
+} ABI_CATCH
 
 int sann_debug_gather_probe(sann_batch_t *b, int32_t mode, int32_t wgs_per_cu, int32_t reps, double *ms_avg,
-                            uint64_t *checksum) {
+                            uint64_t *checksum) try {
   if (!b || !ms_avg || !checksum) return fail(SANN_EINVAL, "NULL argument");
   if (!b->ran || !b->use_fast) return fail(SANN_EINVAL, "run the batch on the fast path first");
   if (reps < 1 || wgs_per_cu < 1 || wgs_per_cu > 16) return fail(SANN_EINVAL, "bad reps / wgs_per_cu");
@@ -1302,9 +1356,9 @@ int sann_debug_gather_probe(sann_batch_t *b, int32_t mode, int32_t wgs_per_cu, i
   *checksum = x;
   *ms_avg = total / reps;
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_debug_unit_arrays(sann_batch_t *b, int32_t *unit_unique, int32_t *cand_cnt, uint32_t *unit_flags, int32_t *unit_T) {
+int sann_debug_unit_arrays(sann_batch_t *b, int32_t *unit_unique, int32_t *cand_cnt, uint32_t *unit_flags, int32_t *unit_T) try {
   if (!b) return fail(SANN_EINVAL, "batch is NULL");
   HIP_TRY(hipSetDevice(b->ix->device));
   HIP_TRY(hipDeviceSynchronize());
@@ -1314,9 +1368,9 @@ int sann_debug_unit_arrays(sann_batch_t *b, int32_t *unit_unique, int32_t *cand_
   if (unit_flags) HIP_TRY(hipMemcpy(unit_flags, b->unit_flags.p, n, hipMemcpyDeviceToHost));
   if (unit_T) HIP_TRY(hipMemcpy(unit_T, b->unit_T.p, n, hipMemcpyDeviceToHost));
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_debug_overflow_reasons(sann_batch_t *b, int32_t *counts8, int32_t *n_inexact) {
+int sann_debug_overflow_reasons(sann_batch_t *b, int32_t *counts8, int32_t *n_inexact) try {
   if (!b || !counts8) return fail(SANN_EINVAL, "NULL argument");
   HIP_TRY(hipSetDevice(b->ix->device));
   std::vector<uint32_t> fl((size_t)b->n_units);
@@ -1328,13 +1382,29 @@ int sann_debug_overflow_reasons(sann_batch_t *b, int32_t *counts8, int32_t *n_in
     if (fl[(size_t)u] & UNIT_OVERFLOW) counts8[std::min<uint64_t>(thr[(size_t)u * 2 + 1], 7)]++;
   if (n_inexact) *n_inexact = b->h_status ? b->h_status[1] : 0;
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_batch_desc_time(sann_batch_t *b, double *desc_ms_total) {
+int sann_debug_plan_slow_tail(int32_t nq, int32_t n_partitions, int32_t n_over, const int32_t *over_units, int32_t n_inexact,
+                              const int32_t *inexact_queries, int32_t *n_units_out, int32_t *n_queries_out) try {
+  if (n_units_out) *n_units_out = 0;
+  if (n_queries_out) *n_queries_out = 0;
+  if (nq < 0 || n_partitions < 1) return fail(SANN_EINVAL, "bad batch shape");
+  int rc = check_status_counts(n_over, n_inexact, (int64_t)nq * n_partitions, nq);
+  if (rc != SANN_OK) return rc;
+  if ((n_over > 0 && !over_units) || (n_inexact > 0 && !inexact_queries)) return fail(SANN_EINVAL, "NULL list");
+  std::vector<int32_t> over(over_units, over_units + n_over), inexact(inexact_queries, inexact_queries + n_inexact), units, queries;
+  rc = plan_slow_tail(nq, n_partitions, over, inexact, units, queries);
+  if (rc != SANN_OK) return rc;
+  if (n_units_out) *n_units_out = (int32_t)units.size();
+  if (n_queries_out) *n_queries_out = (int32_t)queries.size();
+  return SANN_OK;
+} ABI_CATCH
+
+int sann_batch_desc_time(sann_batch_t *b, double *desc_ms_total) try {
   if (!b || !desc_ms_total) return fail(SANN_EINVAL, "NULL argument");
   *desc_ms_total = b->desc_ms_total;
   return SANN_OK;
-}
+} ABI_CATCH
 
 int32_t sann_tweet_shard(int64_t tweet_id, int32_t n_shards) {
   return n_shards <= 1 ? 0 : (int32_t)tweet_shard(mix64((uint64_t)tweet_id), (uint32_t)n_shards);
@@ -1343,11 +1413,11 @@ int32_t sann_tweet_partition(int64_t tweet_id, int32_t n_partitions) {
   return n_partitions <= 1 ? 0 : (int32_t)tweet_partition(mix64((uint64_t)tweet_id), (uint32_t)n_partitions);
 }
 
-int sann_device_synchronize(int32_t device) {
+int sann_device_synchronize(int32_t device) try {
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipDeviceSynchronize());
   return SANN_OK;
-}
+} ABI_CATCH
 
 }  // extern "C"
 sann_index::~sann_index() {
@@ -1355,12 +1425,12 @@ sann_index::~sann_index() {
 }
 extern "C" {
 
-int sann_batch_destroy(sann_batch_t *b) {
+int sann_batch_destroy(sann_batch_t *b) try {
   if (!b) return SANN_OK;
   (void)hipSetDevice(b->ix->device);
   delete b;
   return SANN_OK;
-}
+} ABI_CATCH
 
 // One call = (pooled batch) reset + run + finish + results: the shape a JNI stub binds.  Every concurrent caller works on
 // a batch object of its own, taken from the index's pool and given back afterwards, on that object's own non-blocking
@@ -1370,7 +1440,7 @@ int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_
                               const int64_t *source_tweet_ids, const uint8_t *has_source_tweet,
                               const sann_config_t *configs, int32_t n_configs, const int64_t *scan_offsets,
                               const int32_t *scan_cluster_ids, int64_t *out_ids, double *out_scores,
-                              int32_t out_stride, int32_t *out_counts, int32_t *out_map_sizes) {
+                              int32_t out_stride, int32_t *out_counts, int32_t *out_map_sizes) try {
   if (!index) return fail(SANN_EINVAL, "index is NULL");
   if (variant < 0 || variant > 3) return fail(SANN_EINVAL, "unknown variant");
   sann_batch *b = nullptr;
@@ -1415,24 +1485,24 @@ int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_
   }
   if (rc != SANN_OK) g_err = keep;
   return rc;
-}
+} ABI_CATCH
 
-int sann_host_alloc(int64_t bytes, void **out) {
+int sann_host_alloc(int64_t bytes, void **out) try {
   if (!out || bytes < 0) return fail(SANN_EINVAL, "bad arguments");
   *out = nullptr;
   if (bytes == 0) return SANN_OK;
   HIP_TRY(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
   return SANN_OK;
-}
-int sann_host_free(void *p) {
+} ABI_CATCH
+int sann_host_free(void *p) try {
   if (p) HIP_TRY(hipHostFree(p));
   return SANN_OK;
-}
+} ABI_CATCH
 
 int sann_merge_shards(int32_t device, void *hip_stream, int32_t n_shards, int32_t nq, int32_t stride,
                       int64_t shard_pitch_bytes, const void *d_ids, const void *d_scores, const void *d_counts,
                       const void *d_map_sizes, const void *d_k,
-                      void *d_out_ids, void *d_out_scores, void *d_out_counts, void *d_out_map_sizes) {
+                      void *d_out_ids, void *d_out_scores, void *d_out_counts, void *d_out_map_sizes) try {
   if (n_shards < 1 || nq < 0 || stride < 1 || stride > 1024) return fail(SANN_EINVAL, "bad merge sizes");
   if (nq == 0) return SANN_OK;
   if (!d_ids || !d_scores || !d_counts || !d_map_sizes || !d_k || !d_out_ids || !d_out_scores || !d_out_counts ||
@@ -1445,12 +1515,12 @@ int sann_merge_shards(int32_t device, void *hip_stream, int32_t n_shards, int32_
                               (int64_t *)d_out_ids, (double *)d_out_scores, (int32_t *)d_out_counts,
                               (int32_t *)d_out_map_sizes, nullptr, (hipStream_t)hip_stream));
   return SANN_OK;
-}
+} ABI_CATCH
 
 int sann_merge_shards_cut(int32_t device, void *hip_stream, int32_t n_shards, int32_t nq, int32_t shard_stride,
                           int64_t shard_pitch_bytes, int32_t shard_k, int32_t k, int32_t out_stride, const void *d_ids, const void *d_scores,
                           const void *d_counts, const void *d_map_sizes, void *d_out_ids, void *d_out_scores,
-                          void *d_out_counts, void *d_out_map_sizes, void *d_inexact_count) {
+                          void *d_out_counts, void *d_out_map_sizes, void *d_inexact_count) try {
   if (n_shards < 1 || nq < 0 || shard_stride < 1 || shard_stride > 1024 || out_stride < 1 || out_stride > 1024)
     return fail(SANN_EINVAL, "bad merge sizes");
   if (shard_k < 1 || shard_k > shard_stride || k < 0) return fail(SANN_EINVAL, "bad shard_k / k");
@@ -1465,9 +1535,9 @@ int sann_merge_shards_cut(int32_t device, void *hip_stream, int32_t n_shards, in
                               (int64_t *)d_out_ids, (double *)d_out_scores, (int32_t *)d_out_counts,
                               (int32_t *)d_out_map_sizes, (int32_t *)d_inexact_count, (hipStream_t)hip_stream));
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_debug_wave_sort(int32_t device, int32_t n_waves, uint32_t *values) {
+int sann_debug_wave_sort(int32_t device, int32_t n_waves, uint32_t *values) try {
   if (n_waves < 0 || (n_waves > 0 && !values)) return fail(SANN_EINVAL, "bad arguments");
   if (n_waves == 0) return SANN_OK;
   HIP_TRY(hipSetDevice(device));
@@ -1477,10 +1547,10 @@ int sann_debug_wave_sort(int32_t device, int32_t n_waves, uint32_t *values) {
   HIP_TRY(launch_debug_wave_sort(n_waves, d.as<uint32_t>(), nullptr));
   HIP_TRY(hipMemcpy(values, d.p, (size_t)n_waves * 64 * 4, hipMemcpyDeviceToHost));
   return SANN_OK;
-}
+} ABI_CATCH
 
 int sann_debug_approx(int32_t device, int32_t alg, int32_t n, const double *s, const double *w, double l2norm,
-                      double lognorm, float *out, uint8_t *out_forced, double *eps) {
+                      double lognorm, float *out, uint8_t *out_forced, double *eps) try {
   if (eps) *eps = kApproxEps;
   if (n < 0 || (n > 0 && (!s || !w || !out || !out_forced))) return fail(SANN_EINVAL, "bad arguments");
   if (n == 0) return SANN_OK;
@@ -1496,10 +1566,10 @@ int sann_debug_approx(int32_t device, int32_t alg, int32_t n, const double *s, c
   HIP_TRY(hipMemcpy(out, c.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(out_forced, d.p, (size_t)n, hipMemcpyDeviceToHost));
   return SANN_OK;
-}
+} ABI_CATCH
 
 int sann_debug_normalise(int32_t device, int32_t alg, int32_t n, const double *dot, const double *nsq, double l2norm,
-                         double lognorm, double *out) {
+                         double lognorm, double *out) try {
   if (n < 0 || (n > 0 && (!dot || !nsq || !out))) return fail(SANN_EINVAL, "bad arguments");
   if (n == 0) return SANN_OK;
   HIP_TRY(hipSetDevice(device));
@@ -1512,6 +1582,6 @@ int sann_debug_normalise(int32_t device, int32_t alg, int32_t n, const double *d
   HIP_TRY(launch_debug_normalise(alg, n, a.as<double>(), b.as<double>(), l2norm, lognorm, c.as<double>(), nullptr));
   HIP_TRY(hipMemcpy(out, c.p, (size_t)n * 8, hipMemcpyDeviceToHost));
   return SANN_OK;
-}
+} ABI_CATCH
 
 }  // extern "C"

@@ -22,6 +22,8 @@
 #include "sann_host.h"
 
 using sann_host::fail;
+#include "abi_guard.h"
+#define ABI_CATCH catch (...) { return abi_guard::caught(sann_host::fail, SANN_ENOMEM, SANN_EINTERNAL); }
 
 struct sann_comm {
   ncclComm_t comm = nullptr;
@@ -36,16 +38,16 @@ struct sann_comm {
 
 extern "C" {
 
-int sann_comm_unique_id(void *id128) {
+int sann_comm_unique_id(void *id128) try {
   if (!id128) return fail(SANN_EINVAL, "id128 is NULL");
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   ncclUniqueId id;
   NCCL_TRY(ncclGetUniqueId(&id));
   memcpy(id128, &id, sizeof id);
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_comm_create(int32_t device, int32_t rank, int32_t world, const void *id128, sann_comm_t **out) {
+int sann_comm_create(int32_t device, int32_t rank, int32_t world, const void *id128, sann_comm_t **out) try {
   if (!out) return fail(SANN_EINVAL, "out is NULL");
   *out = nullptr;
   if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(SANN_EINVAL, "bad rank / world / id");
@@ -64,24 +66,24 @@ int sann_comm_create(int32_t device, int32_t rank, int32_t world, const void *id
   }
   *out = c;
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_comm_info(const sann_comm_t *c, int32_t *rank, int32_t *world) {
+int sann_comm_info(const sann_comm_t *c, int32_t *rank, int32_t *world) try {
   if (!c) return fail(SANN_EINVAL, "comm is NULL");
   if (rank) *rank = c->rank;
   if (world) *world = c->world;
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_comm_destroy(sann_comm_t *c) {
+int sann_comm_destroy(sann_comm_t *c) try {
   if (!c) return SANN_OK;
   (void)hipSetDevice(c->device);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   delete c;
   return SANN_OK;
-}
+} ABI_CATCH
 
-int sann_exchange_to_owners(sann_comm_t *c, void *hip_stream, const void *d_send, void *d_recv, int64_t chunk_bytes) {
+int sann_exchange_to_owners(sann_comm_t *c, void *hip_stream, const void *d_send, void *d_recv, int64_t chunk_bytes) try {
   if (!c) return fail(SANN_EINVAL, "comm is NULL");
   if (chunk_bytes < 0 || (chunk_bytes > 0 && (!d_send || !d_recv))) return fail(SANN_EINVAL, "bad buffers");
   if (chunk_bytes == 0) return SANN_OK;
@@ -101,10 +103,10 @@ int sann_exchange_to_owners(sann_comm_t *c, void *hip_stream, const void *d_send
   }
   NCCL_TRY(ncclGroupEnd());
   return SANN_OK;
-}
+} ABI_CATCH
 
 int sann_owner_message_layout(int32_t queries_per_owner, int32_t stride, int64_t *chunk_bytes, int64_t *off_scores,
-                              int64_t *off_counts, int64_t *off_map_sizes) {
+                              int64_t *off_counts, int64_t *off_map_sizes) try {
   if (queries_per_owner < 0 || stride < 1) return fail(SANN_EINVAL, "bad sizes");
   // [ids int64[n][stride] | score bits fp64[n][stride] | counts int32[n] | map sizes int32[n]]: a multiple of 8 bytes
   const int64_t arr = (int64_t)queries_per_owner * stride * 8;
@@ -113,6 +115,6 @@ int sann_owner_message_layout(int32_t queries_per_owner, int32_t stride, int64_t
   if (off_map_sizes) *off_map_sizes = 2 * arr + 4 * (int64_t)queries_per_owner;
   if (chunk_bytes) *chunk_bytes = 2 * arr + 8 * (int64_t)queries_per_owner;
   return SANN_OK;
-}
+} ABI_CATCH
 
 }  // extern "C"

@@ -40,6 +40,8 @@
 using namespace sann;
 using sann_host::DevBuf;
 using sann_host::fail;
+#include "abi_guard.h"
+#define ABI_CATCH catch (...) { return abi_guard::caught(sann_host::fail, SANN_ENOMEM, SANN_EINTERNAL); }
 
 namespace {
 
@@ -344,7 +346,7 @@ GenParams gen_params(const sann_synth_params_t *sp) {
 
 extern "C" {
 
-int sann_index_build_synthetic(const sann_index_options_t *opts, const sann_synth_params_t *sp, sann_index_t **out) {
+int sann_index_build_synthetic(const sann_index_options_t *opts, const sann_synth_params_t *sp, sann_index_t **out) try {
   if (!out) return fail(SANN_EINVAL, "out is NULL");
   *out = nullptr;
   if (!opts || !sp) return fail(SANN_EINVAL, "NULL argument");
@@ -494,13 +496,13 @@ int sann_index_build_synthetic(const sann_index_options_t *opts, const sann_synt
   guard.p = nullptr;
   *out = ix;
   return SANN_OK;
-}
+} ABI_CATCH
 
 // The cluster -> top tweets provider on the device: raw store entries in, index out.
 int sann_index_build_from_postings(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
                                    const int64_t *list_offsets, const int64_t *tweet_ids, const double *values,
                                    const double *scaled_times, int64_t now_ms, int64_t half_life_ms, int32_t max_results,
-                                   sann_index_t **out) {
+                                   sann_index_t **out) try {
   if (!out) return fail(SANN_EINVAL, "out is NULL");
   *out = nullptr;
   if (!opts) return fail(SANN_EINVAL, "opts is NULL");
@@ -613,10 +615,10 @@ int sann_index_build_from_postings(const sann_index_options_t *opts, int32_t n_l
   guard.p = nullptr;
   *out = ix;
   return SANN_OK;
-}
+} ABI_CATCH
 
 int sann_synth_tweet_embeddings(int32_t device, const sann_synth_params_t *sp, int64_t t0, int32_t n, int32_t *counts,
-                                int32_t *cluster_ids, double *scores) {
+                                int32_t *cluster_ids, double *scores) try {
   if (!sp || n < 0 || t0 < 0 || t0 + n > sp->n_tweets || (n > 0 && (!counts || !cluster_ids || !scores)))
     return fail(SANN_EINVAL, "bad arguments");
   if (n == 0) return SANN_OK;
@@ -632,11 +634,11 @@ int sann_synth_tweet_embeddings(int32_t device, const sann_synth_params_t *sp, i
   HIP_TRY(hipMemcpy(cluster_ids, dl.p, (size_t)n * 64 * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(scores, ds.p, (size_t)n * 64 * 8, hipMemcpyDeviceToHost));
   return SANN_OK;
-}
+} ABI_CATCH
 
 int sann_synth_exact_cosine_topk(int32_t device, const sann_synth_params_t *sp, int32_t nq, const int64_t *emb_offsets,
                                  const int32_t *emb_cluster_ids, const double *emb_scores, int32_t k, int64_t *out_ids,
-                                 double *out_cos, int32_t *out_counts) {
+                                 double *out_cos, int32_t *out_counts) try {
   if (!sp || nq < 0 || k < 1 || (nq > 0 && (!emb_offsets || !out_ids || !out_cos || !out_counts)))
     return fail(SANN_EINVAL, "bad arguments");
   if (nq == 0) return SANN_OK;
@@ -713,7 +715,7 @@ int sann_synth_exact_cosine_topk(int32_t device, const sann_synth_params_t *sp, 
     out_counts[q] = m;
   }
   return SANN_OK;
-}
+} ABI_CATCH
 
 int64_t sann_synth_tweet_id(int64_t t, int64_t n_tweets, int64_t now_ms, int32_t window_hours) {
   const int64_t span = (int64_t)window_hours * 3600000ll;

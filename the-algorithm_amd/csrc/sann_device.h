@@ -56,6 +56,7 @@ struct IndexView {
   int32_t n_rows;
   int32_t P;      // partitions (power of two)
   int32_t log2P;
+  uint32_t n_postings;  // postings held (< 2^32 per shard): device-written positions are checked against it before use
 };
 
 // entries of a unit's descriptor row (BatchView::desc): 64 while every query of the batch scans <= 64 clusters, else 128

@@ -99,6 +99,7 @@ struct sann_index {
     v.n_rows = (int32_t)cluster_ids.size();
     v.P = P;
     v.log2P = log2P;
+    v.n_postings = (uint32_t)n_postings;
     return v;
   }
   int row_of(int32_t cluster) const {

@@ -630,6 +630,7 @@ __global__ __launch_bounds__(WG, 4) void merge_kernel(IndexView ix, BatchView b,
   MSTAMP(1);  // offsets
   int best_n = 0;  // entries currently in s_e2
   int u_begin = 0;
+  bool bad_handover = false;  // this thread met a handed-over candidate that points outside the index / the query
   while (u_begin < P) {
     // units [u_begin, u_end) such that best + their entries fit (a single list always fits:
     // MERGE_LDS - SURV >= any per-unit capacity)
@@ -683,8 +684,16 @@ __global__ __launch_bounds__(WG, 4) void merge_kernel(IndexView ix, BatchView b,
           ps[rr] = Posting{0, 0.0};
           wq[rr] = 0.0;
           if (r < R && kh[r] == CAND_DEFERRED) {
-            ps[rr] = ix.postings[(uint32_t)kid[r]];
-            wq[rr] = b.scan_w[h.scan_begin + (int)((uint64_t)kid[r] >> 32)];
+            // (posting position, cluster sequence number) were written by the unit kernel: checked against the index and
+            // the query before they address anything -- a corrupted hand-over becomes an unproven query (re-answered
+            // exactly by the general path), never a faulting load
+            if ((uint32_t)kid[r] < ix.n_postings && (uint32_t)((uint64_t)kid[r] >> 32) < (uint32_t)h.n_scan) {
+              ps[rr] = ix.postings[(uint32_t)kid[r]];
+              wq[rr] = b.scan_w[h.scan_begin + (int)((uint64_t)kid[r] >> 32)];
+            } else {
+              kh[r] = CAND_DROPPED;
+              bad_handover = true;
+            }
           }
         }
 #pragma unroll
@@ -846,7 +855,7 @@ __global__ __launch_bounds__(WG, 4) void merge_kernel(IndexView ix, BatchView b,
   if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; }
   __syncthreads();
   if (msz) atomicAdd(&s_ctl[0], msz);
-  if (inexact) atomicOr(&s_ctl[1], 1);
+  if (inexact || bad_handover) atomicOr(&s_ctl[1], 1);
   if (t_sum) {
     atomicMax((unsigned *)&s_ctl[2], t_max);
     atomicAdd((unsigned *)&s_ctl[3], t_sum);
@@ -933,6 +942,7 @@ __global__ __launch_bounds__(WG, (E <= 4 ? 6 : 4)) void merge_wave_kernel(IndexV
     }
   }
   // candidates handed over as (cluster, posting position): fetch and score (as merge_kernel's staging does), four at a time
+  bool bad_handover = false;
 #pragma unroll
   for (int r0 = 0; r0 < E; r0 += 4) {
     Posting ps[4];
@@ -943,8 +953,13 @@ __global__ __launch_bounds__(WG, (E <= 4 ? 6 : 4)) void merge_wave_kernel(IndexV
       ps[rr] = Posting{0, 0.0};
       wq[rr] = 0.0;
       if (kh[r] == CAND_DEFERRED) {
-        ps[rr] = ix.postings[(uint32_t)kid[r]];
-        wq[rr] = b.scan_w[h.scan_begin + (int)((uint64_t)kid[r] >> 32)];
+        if ((uint32_t)kid[r] < ix.n_postings && (uint32_t)((uint64_t)kid[r] >> 32) < (uint32_t)h.n_scan) {  // (as merge_kernel)
+          ps[rr] = ix.postings[(uint32_t)kid[r]];
+          wq[rr] = b.scan_w[h.scan_begin + (int)((uint64_t)kid[r] >> 32)];
+        } else {
+          kh[r] = CAND_DROPPED;
+          bad_handover = true;
+        }
       }
     }
 #pragma unroll
@@ -1007,7 +1022,7 @@ __global__ __launch_bounds__(WG, (E <= 4 ? 6 : 4)) void merge_wave_kernel(IndexV
   }
   // candidateScoresMap.size (:102), the exactness proof and the statistics, as merge_kernel
   const bool inexact = lane < P && k > 0 && (pf_flags & UNIT_TRUNCATED) && key_gt(pf_thi, pf_tlo, xk_hi, xk_lo);
-  const unsigned long long any_inexact = __ballot(inexact);
+  const unsigned long long any_inexact = __ballot(inexact || bad_handover);
   const int msz = __builtin_amdgcn_readlane(wave_incl_scan_i32(pf_unique), 63);
   const uint32_t t_sum = (uint32_t)__builtin_amdgcn_readlane(wave_incl_scan_i32((int)pf_T), 63);
   const uint32_t t_max = wave_max_u32(pf_T);

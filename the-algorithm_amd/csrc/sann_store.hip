@@ -32,6 +32,8 @@
 using namespace sann;
 using sann_host::DevBuf;
 using sann_host::fail;
+#include "abi_guard.h"
+#define ABI_CATCH catch (...) { return abi_guard::caught(sann_host::fail, SANN_ENOMEM, SANN_EINTERNAL); }
 
 namespace {
 
@@ -188,7 +190,7 @@ extern "C" int sann_topk_merge(int32_t device, int32_t n_lists, const int64_t *a
                                const double *a_values, const double *a_scaled_times, const int64_t *b_offsets,
                                const int64_t *b_ids, const double *b_values, const double *b_scaled_times, int32_t top_k,
                                double threshold, int64_t oldest_tweet_id, int64_t out_capacity, int64_t *out_offsets,
-                               int64_t *out_ids, double *out_values, double *out_scaled_times) {
+                               int64_t *out_ids, double *out_values, double *out_scaled_times) try {
   if (n_lists < 0 || top_k < 0) return fail(SANN_EINVAL, "n_lists / top_k must not be negative");
   if (!out_offsets) return fail(SANN_EINVAL, "out_offsets is NULL");
   if (n_lists > 0 && (!a_offsets || !b_offsets)) return fail(SANN_EINVAL, "offset arrays are NULL");
@@ -277,4 +279,4 @@ extern "C" int sann_topk_merge(int32_t device, int32_t n_lists, const int64_t *a
     std::copy_n(h_t.data() + src, cnt[(size_t)i], out_scaled_times + dst);
   }
   return SANN_OK;
-}
+} ABI_CATCH

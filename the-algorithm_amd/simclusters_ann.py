@@ -181,6 +181,7 @@ _PROTOS = {
     "sann_tweet_partition": (C.c_int32, [C.c_int64, C.c_int32]),
     "sann_device_synchronize": (C.c_int, [C.c_int32]),
     "sann_debug_overflow_reasons": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sann_debug_plan_slow_tail": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sann_debug_gather_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "sann_debug_unit_arrays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sann_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
@@ -213,6 +214,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # The launcher's part of the contract: batches in flight use several HIP streams, and the
+    # runtime reads GPU_MAX_HW_QUEUES once, when it initialises -- so it is set here, by the process that hosts the
+    # library and before anything touches HIP, never by the library (sann_runtime_advice() reports a smaller value).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     # One HIP runtime per process.  torch bundles its own libamdhip64.so.7 and always loads it
     # (RPATH $ORIGIN); ours is found by soname, so it binds to whichever copy is loaded first.
     # If torch will be used in this process it therefore has to be imported BEFORE the dlopen

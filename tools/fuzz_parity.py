@@ -15,7 +15,10 @@ import _pkg  # noqa: E402
 import oracle  # noqa: E402
 
 
-def one_case(pkg, seed):
+def one_case(pkg, seed, wild=False):
+    """wild: lists the store's contract (score > 0, sorted descending: TopKTweetsForClusterReadableStore.scala:211-229)
+    rules out but the operator takes as they come (ApproximateCosineSimilarity.scala:87 reads position i of whatever it is
+    given): shuffled order, negative and zero scores.  sann_index_build keeps positions as given, so must the result."""
     rng = np.random.default_rng(seed)
     n_tweets = int(rng.choice([3000, 20_000, 80_000, 250_000]))
     n_clusters = int(rng.choice([40, 300, 1500, 6000]))
@@ -32,6 +35,14 @@ def one_case(pkg, seed):
         for i in range(len(co.cluster_ids)):
             b, e = co.list_offsets[i], co.list_offsets[i + 1]
             o = np.lexsort((co.tweet_ids[b:e], -co.scores[b:e]))
+            co.tweet_ids[b:e] = co.tweet_ids[b:e][o]; co.scores[b:e] = co.scores[b:e][o]
+    if wild:
+        flip = rng.random(len(co.scores))
+        co.scores[flip < 0.10] *= -1.0
+        co.scores[flip > 0.96] = 0.0
+        for i in range(len(co.cluster_ids)):
+            b, e = co.list_offsets[i], co.list_offsets[i + 1]
+            o = rng.permutation(e - b)
             co.tweet_ids[b:e] = co.tweet_ids[b:e][o]; co.scores[b:e] = co.scores[b:e][o]
     P = int(rng.choice([1, 2, 8, 32, 64]))
     variant = int(rng.choice([0, 0, 1, 2]))
@@ -66,11 +77,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--wild", action="store_true", help="unsorted lists with negative and zero scores")
     a = ap.parse_args()
     pkg = _pkg.load_package()
     t0, n, seed = time.time(), 0, a.seed * 100_000
     while time.time() - t0 < a.seconds:
-        bad = one_case(pkg, seed)
+        bad = one_case(pkg, seed, wild=a.wild)
         if bad:
             print("MISMATCH", bad, flush=True)
             sys.exit(1)
