@@ -70,7 +70,11 @@ def main():
                          "rehearse the N > 1 code path with several ranks sharing one GPU")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="N = 1 only: run the sharded path (process group, all-to-all, owner merge) with one shard")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight: consecutive steps alternate between this many batch objects / HIP streams")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight: consecutive steps alternate between this many HIP streams")
+    ap.add_argument("--rotate", type=int, default=8,
+                    help="distinct prepared query batches the timed loop rotates through (each its own 1024*N synthetic users): 8 "
+                         "batches scan ~1.9 GB of distinct postings, beyond L2 (32 MB) + Infinity Cache (256 MB), so no step finds "
+                         "its postings cached from its own previous run; 1 = replay one batch (round 1-2 behaviour)")
     ap.add_argument("--serial-kernels", action="store_true",
                     help="batches in flight, but a batch's unit kernel waits for the previous batch's merge kernel (only the descriptor kernel and the host overlap)")
     ap.add_argument("--no-overlap", action="store_true", help="one batch at a time on one stream (and, sharded, exchange and owner merge on that stream too)")
@@ -146,7 +150,16 @@ def main():
         # N = 4: P = 16 / 8 / 4 -> 0.374 / 0.290 / 0.270; N = 8: P = 8 / 4 -> 0.383 / 0.308; no unit falls back in any)
         p = max(4, (args.partitions or 32) // world)
         args.partitions = 1 << (p.bit_length() - 1)
+    # query sets: set 0 is SURVEY 8(d)'s batch (seed 20260105); sets 1.. are further draws of the same user model
+    n_rot = max(1, args.rotate)
+    n_sets = max(n_rot, args.e2e_query_sets if not (world > 1 or args.exercise_exchange) else 1)
     offs, cids, scs = pkg.corpus.make_queries(nq)
+    qsets = [(offs, cids, scs)]
+    if n_sets > 1:
+        o_all, c_all, s_all = pkg.corpus.make_queries(nq * (n_sets - 1), seed=pkg.corpus.QUERY_SEED + 1)
+        for i in range(n_sets - 1):
+            lo, hi = o_all[i * nq], o_all[(i + 1) * nq]
+            qsets.append((o_all[i * nq:(i + 1) * nq + 1] - lo, c_all[lo:hi], s_all[lo:hi]))
     now_ms = pkg.corpus.NOW_MS
     if args.corpus == "device":
         index = pkg.ClusterTweetIndex.synthetic(args.tweets, pkg.corpus.N_CLUSTERS, seed=pkg.corpus.CORPUS_SEED,
@@ -217,9 +230,12 @@ def main():
         # descriptor / unit kernels run beside batch i's merge kernel (LDS-bound, one round of workgroups), and the
         # host's per-batch stream wait + status check (sann_batch_finish) is off the GPU's critical path.  Every batch
         # is complete (finished, checked, and when sharded exchanged and merged) before the timed region ends.
-        qbs = [pkg.QueryBatch(index, offs, cids, scs, cfg_run, now_ms=now_ms) for _ in range(depth)]
+        # `depth` streams, `n_rot` prepared batches (own workspaces and outputs, DISTINCT queries): step s runs batch
+        # s % n_rot on stream s % depth
+        n_obj = max(depth, n_rot)
+        qbs = [pkg.QueryBatch(index, *qsets[j % n_rot], cfg_run, now_ms=now_ms) for j in range(n_obj)]
         stride = qbs[0].stride
-        launched = []  # slots whose batch is enqueued but not yet finished, oldest first
+        launched = []  # (batch, stream slot) enqueued but not yet finished, oldest first
         n_steps_done = [0]
         alone = [False]  # True: one batch at a time, nothing overlapped (the per-kernel timings after the timed region)
 
@@ -232,10 +248,10 @@ def main():
             # one packed message per owner: [ids nql*stride | score bits nql*stride | counts nql | map sizes nql]
             chunk, _offsets = pkg.sharding.owner_message_layout(nql, stride)  # bytes, a multiple of 8
             arr = nql * stride * 8
-            sends = [torch.zeros(world * chunk, dtype=torch.uint8, device="cuda") for _ in range(depth)]
+            sends = [torch.zeros(world * chunk, dtype=torch.uint8, device="cuda") for _ in range(n_obj)]
             recv = torch.zeros_like(sends[0])  # [world shards][chunk]: this rank's queries, one chunk per shard
             rp = recv.data_ptr()
-            sent = [None] * depth  # event: the exchange that read sends[slot] has finished
+            sent = [None] * n_obj  # event: the exchange that read sends[batch] has finished
             ready = [torch.cuda.Event() for _ in sends]  # event: the batch in sends[slot] is final
             for j, qb in enumerate(qbs):
                 sp = sends[j].data_ptr()
@@ -244,7 +260,7 @@ def main():
             out_sc = torch.zeros((nql, K), dtype=torch.float64, device="cuda")
             out_cnt = torch.zeros(nql, dtype=torch.int32, device="cuda")
             out_msz = torch.zeros(nql, dtype=torch.int32, device="cuda")
-            d_k = qbs[0].device_k() + rank * nql * 4
+            d_ks = [qb.device_k() + rank * nql * 4 for qb in qbs]
             d_bad = torch.zeros(1, dtype=torch.int32, device="cuda")  # queries whose cut per-shard lists could not prove the merge exact
             torch.cuda.synchronize()  # the buffers were zero-filled on the default stream; they are used on others
 
@@ -260,14 +276,14 @@ def main():
                                                  ctypes.c_void_p(recv.data_ptr()), chunk)
                 assert rc == 0, lib.sann_last_error()
 
-        def post(slot):
+        def post(j, slot):
             """Exchange + owner merge of a finished batch, on the side stream."""
-            ready[slot].record(t_streams[slot])
+            ready[j].record(t_streams[slot])
             with torch.cuda.stream(side_stream):
-                side_stream.wait_event(ready[slot])
-                exchange(sends[slot], recv, side_stream.cuda_stream)
-                sent[slot] = torch.cuda.Event()
-                sent[slot].record(side_stream)
+                side_stream.wait_event(ready[j])
+                exchange(sends[j], recv, side_stream.cuda_stream)
+                sent[j] = torch.cuda.Event()
+                sent[j].record(side_stream)
                 side = ctypes.c_void_p(side_stream.cuda_stream)
                 if shard_k < K:
                     rc = lib.sann_merge_shards_cut(local_rank, side, world, nql, stride, chunk, shard_k, K, K,
@@ -277,34 +293,42 @@ def main():
                 else:
                     rc = lib.sann_merge_shards(local_rank, side, world, nql, stride, chunk, rp, rp + arr,
                                                rp + 2 * arr, rp + 2 * arr + 4 * nql,
-                                               d_k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr())
+                                               d_ks[j], out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr())
                 assert rc == 0, lib.sann_last_error()
 
-        def retire(slot):
+        def retire(j, slot):
             # waits for the batch's stream and re-runs whatever the fast path flagged, before anything is sent
-            qbs[slot].finish(streams[slot])
+            qbs[j].finish(streams[slot])
             if sharded:
-                post(slot)
+                post(j, slot)
 
-        def step():
-            slot = n_steps_done[0] % depth
+        prev = [None]   # the batch of the previous step (its unit kernel is what this step's unit kernel waits for)
+        runs = [0] * n_obj  # timed steps each batch object served
+
+        def step(force_j=None):
+            s_no = n_steps_done[0]
+            slot, j = s_no % depth, (s_no % n_obj if force_j is None else force_j)
             n_steps_done[0] += 1
-            if sharded and sent[slot] is not None:
-                t_streams[slot].wait_event(sent[slot])  # the message buffer is free again
+            runs[j] += 1
+            if sharded and sent[j] is not None:
+                t_streams[slot].wait_event(sent[j])  # the message buffer is free again
             # asynchronous: descriptor, unit and merge kernels of this batch; the unit kernel waits on the GPU for the
             # previous batch's unit kernel (the dominant kernels run one at a time, everything else overlaps)
-            if depth > 1 and not alone[0]:
-                qbs[slot].run_after(streams[slot], qbs[(slot - 1) % depth], after_merge=args.serial_kernels)
+            if depth > 1 and not alone[0] and prev[0] is not None:
+                qbs[j].run_after(streams[slot], qbs[prev[0]], after_merge=args.serial_kernels)
+            elif depth > 1 and not alone[0]:
+                qbs[j].run_after(streams[slot], None, after_merge=args.serial_kernels)
             else:
-                qbs[slot].run(streams[slot])
-            launched.append(slot)
+                qbs[j].run(streams[slot])
+            prev[0] = j
+            launched.append((j, slot))
             # keep depth-1 batches queued behind the one the host now waits for (none when timing kernels alone)
             while len(launched) > (0 if alone[0] else depth - 1):
-                retire(launched.pop(0))
+                retire(*launched.pop(0))
 
         def sync():
             while launched:
-                retire(launched.pop(0))
+                retire(*launched.pop(0))
             if sharded:
                 torch.cuda.synchronize()
                 dist.barrier()
@@ -331,11 +355,14 @@ def main():
         sync()
         for qb in qbs:
             qb.set_profiling(1)
+        for j in range(n_obj):
+            runs[j] = 0
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         sync()
         elapsed = time.perf_counter() - t0
+        runs_timed = list(runs)
         unit_ms = sum(qb.kernel_times()[0] for qb in qbs)
         n_timed = sum(qb.kernel_times()[2] for qb in qbs)
         for qb in qbs:
@@ -352,24 +379,36 @@ def main():
         merge_ms, desc_ms = merge_ms * n_timed / n_aux, desc_ms * n_timed / n_aux  # reported as per-launch averages below
         for qb in qbs:
             qb.set_profiling(False)
-        last = qbs[(n_steps_done[0] - 1) % depth]  # the batch of the last step
-        # ---- results of the last step (this rank's own queries when sharded) -----------------------
+        # ---- results: candidates every prepared batch returns (the rotated batches differ), and batch 0's answer (query
+        # set 0 = SURVEY 8(d)'s seed; this rank's own queries when sharded) for the checks below ----------------------
+        cand_of = [0] * n_obj
         if sharded:
-            torch.cuda.synchronize()
+            # the owners' merged outputs are one buffer: one more pass, a batch at a time, batch 0 last
+            alone[0] = True
+            for j in reversed(range(n_obj)):
+                step(force_j=j)
+                sync()
+                cand_of[j] = int(out_cnt.sum().item())
+            alone[0] = False
             ids, scores, counts, msz = out_ids.cpu().numpy(), out_sc.cpu().numpy(), out_cnt.cpu().numpy(), out_msz.cpu().numpy()
         else:
-            ids, scores, counts, msz = last.results()
-        st = last.stats()
+            for j in reversed(range(n_obj)):
+                ids, scores, counts, msz = qbs[j].results()
+                cand_of[j] = int(counts.sum())
         n_fallback_units = sum(int(qb.stats().n_fallback_units) for qb in qbs)
-        candidates_per_step = int(counts.sum())
+        n_runs_timed = max(sum(runs_timed), 1)
+        candidates_timed = sum(r * c for r, c in zip(runs_timed, cand_of))  # over the timed steps, this rank's queries
+        # per-launch averages over the timed steps (sum_q P_q*16 + n*12, + k_out*16 added below)
+        postings_per_step = sum(r * int(qb.stats().postings_scanned) for r, qb in zip(runs_timed, qbs)) / n_runs_timed
+        alg_bytes = int(sum(r * (int(qb.stats().algorithmic_bytes) + c * 16) for r, qb, c in zip(runs_timed, qbs, cand_of)) / n_runs_timed)
         if sharded:
             dev = "cpu" if args.backend == "gloo" else "cuda"
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-            tc = torch.tensor([candidates_per_step, int(d_bad.item())], dtype=torch.int64, device=dev)
+            tc = torch.tensor([candidates_timed, int(d_bad.item())], dtype=torch.int64, device=dev)
             dist.all_reduce(tc, op=dist.ReduceOp.SUM)
-            candidates_per_step = int(tc[0].item())  # whole job: every rank's queries
+            candidates_timed = int(tc[0].item())  # whole job: every rank's queries
             if int(tc[1].item()) > 0 and shard_k < K:
                 # some query's merged top-k could not be proven exact from the cut lists: the whole measurement
                 # is repeated with full-length per-shard lists (expected never; the proof is checked every batch)
@@ -379,7 +418,7 @@ def main():
                     qb.close()
                 continue
         break
-    value = candidates_per_step * args.steps / elapsed
+    value = candidates_timed / elapsed
 
     # ---- end-to-end leg: the boundary call itself, fresh queries every step ---------------------------------------
     # sann_get_tweet_candidates = host arrays in -> packed H2D -> device-side query preparation -> descriptor / unit /
@@ -391,12 +430,6 @@ def main():
         import threading
 
         sa = pkg.simclusters_ann
-        n_sets = max(1, args.e2e_query_sets)
-        qsets = [(offs, cids, scs)]
-        o_all, c_all, s_all = pkg.corpus.make_queries(nq * (n_sets - 1), seed=pkg.corpus.QUERY_SEED + 1) if n_sets > 1 else (None, None, None)
-        for i in range(n_sets - 1):
-            lo, hi = o_all[i * nq], o_all[(i + 1) * nq]
-            qsets.append((o_all[i * nq:(i + 1) * nq + 1] - lo, c_all[lo:hi], s_all[lo:hi]))
         n_thr = max(1, args.e2e_threads)
         outs = [(sa.pinned_array((nq, K), np.int64), sa.pinned_array((nq, K), np.float64), sa.pinned_array((nq,), np.int32),
                  sa.pinned_array((nq,), np.int32)) for _ in range(n_thr)]
@@ -506,9 +539,9 @@ def main():
 
     # ---- roofline of the dominant kernel (unit kernel: gather + accumulate + select) -----------
     # algorithmic bytes per launch: sum_q P_q*16 + n*12 + k_out*16
-    alg_bytes = int(st.algorithmic_bytes) + int(counts.sum()) * 16
     unit_avg_ms = unit_ms / max(n_timed, 1)
     achieved = alg_bytes / (unit_avg_ms * 1e-3) / 1e9 if unit_avg_ms > 0 else 0.0
+    distinct_clusters = int(len(np.unique(np.concatenate([q[1] for q in qsets[:n_rot]]))))
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic_bytes(args, nq, world), "kernel": "sann::unit_fast_kernel (gather+accumulate+select)",
             "kernel_avg_ms": unit_avg_ms, "desc_kernel_avg_ms": desc_ms / max(n_timed, 1),
@@ -516,6 +549,11 @@ def main():
             # the timed region keeps batches in flight, so its unit kernel shares the GPU with the previous batch's
             # merge kernel and the next batch's descriptor kernel; *_alone = the same launch with the GPU to itself
             # (steps after the timed region, one batch at a time), as are the desc / merge figures above
+            "frac_against": ("HBM3E 8 TB/s: the timed loop rotates %d distinct prepared batches (%d distinct scanned clusters, up to "
+                             "%.2f GB of distinct postings between two runs of the same batch), beyond L2 32 MB + Infinity Cache "
+                             "256 MB; the corpus's hottest clusters (Zipf head, shared by all batches) still hit in cache, as they "
+                             "would in service" % (n_rot, distinct_clusters, distinct_clusters * 800 * 16 / 1e9)) if n_rot >= 8 else
+                            "HBM3E 8 TB/s, but the loop replays %d batch(es): their postings can stay in the 256 MB Infinity Cache" % n_rot,
             "kernel_avg_ms_alone": unit_alone_ms,
             "frac_alone": (alg_bytes / (unit_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if unit_alone_ms > 0 else 0.0}
 
@@ -538,10 +576,12 @@ def main():
                    "max_top_tweets_per_cluster": 800, "algorithm": args.alg, "index_cap": 2000,
                    "partitions": index.info().n_partitions, "sharding": "none" if world == 1 else "tweet-hash",
                    "shard_list_length": shard_k, "queries_not_proven_by_cut_lists": inexact_seen,
-                   "batches_in_flight": depth,
+                   "batches_in_flight": depth, "rotated_query_batches": n_rot,
+                   "distinct_scanned_clusters_in_rotation": distinct_clusters,
+                   "distinct_posting_bytes_in_rotation_upper": distinct_clusters * 800 * 16,
                    "corpus": args.corpus, "index_postings": int(index.info().n_postings_total)},
         "queries_per_sec": nq * args.steps / elapsed,
-        "postings_per_sec": int(st.postings_scanned) * args.steps / elapsed,
+        "postings_per_sec": postings_per_step * args.steps / elapsed,
         "recall_at_400_parity": recall_parity,
         "recall_at_400_quality": recall_quality,
         "quality_checked_queries": (min(args.quality_queries, nq) if recall_quality is not None else 0),
