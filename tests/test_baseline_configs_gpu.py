@@ -153,3 +153,97 @@ def test_c4_dense_5m_vectors_k200(pkg):
         assert clear.sum() > k // 2
         assert np.array_equal(ids[q][clear], r_i[clear])
     ix.close()
+
+
+def _float64_reference_topk(ix, pq, n, k, step):
+    """Exact top-(k+1) of `pq` (float64 queries as the index sees them) over the index's stored vectors: a float32 BLAS
+    pass per chunk shortlists 4k positions per query (its 1e-6 error cannot move a true top-(k+1) member out of a 4k
+    shortlist), the shortlist is re-scored in float64."""
+    nqs = pq.shape[0]
+    short = 4 * k
+    cand_s = np.full((nqs, 0), -np.inf, np.float32)
+    cand_i = np.zeros((nqs, 0), np.int64)
+    pq32 = pq.astype(np.float32)
+    for i0 in range(0, n, step):
+        x = ix.stored_vectors(i0, min(step, n - i0))
+        sc = pq32 @ x.T
+        part = np.argpartition(-sc, short, axis=1)[:, :short]
+        cand_s = np.concatenate([cand_s, np.take_along_axis(sc, part, axis=1)], axis=1)
+        cand_i = np.concatenate([cand_i, part.astype(np.int64) + i0], axis=1)
+        if cand_s.shape[1] > short:
+            keep = np.argpartition(-cand_s, short, axis=1)[:, :short]
+            cand_s = np.take_along_axis(cand_s, keep, axis=1)
+            cand_i = np.take_along_axis(cand_i, keep, axis=1)
+        del x, sc
+    best_d = np.empty((nqs, k + 1))
+    best_i = np.empty((nqs, k + 1), np.int64)
+    for j in range(nqs):
+        rows = np.stack([ix.stored_vectors(int(i), 1)[0] for i in cand_i[j]]).astype(np.float64)
+        dd = 1.0 - rows @ pq[j]
+        order = np.lexsort((cand_i[j], dd))[:k + 1]
+        best_d[j], best_i[j] = dd[order], cand_i[j][order]
+    return best_d, best_i
+
+
+def test_c4_dense_50m_vectors_k200_at_size(pkg):
+    """BASELINE configs[3] at its stated size: 50M x d = 256 fp16 vectors, 1024 queries, k = 200 (the dense
+    leg stopped at 5M).  Size-independent properties for every query (k results, ascending distances, distinct ids), and
+    4 queries against a float64 scan of ALL 50M stored vectors (distances within 1e-5; ids equal wherever the reference
+    distances are separated by more than the tolerance) -- BruteForceIndex.scala:66-91 restated on the host."""
+    da = pkg.dense_ann
+    n, d, k, nq = 50_000_000, 256, 200, 1024
+    ix = da.BruteForceIndex.synthetic(da.DistanceMetric.Cosine, n, d, seed=3)
+    rng = np.random.default_rng(5)
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    ids, dist, cnt = ix.search(queries, k)
+    assert np.all(cnt == k)
+    assert np.all(np.diff(dist, axis=1) >= 0)
+    assert ids.min() >= 0 and ids.max() < n
+    for q in range(0, nq, 61):
+        assert len(np.unique(ids[q])) == k
+    qs = [0, 341, 682, 1023]
+    pq = queries[qs].astype(np.float64)
+    pq /= np.sqrt((pq ** 2).sum(axis=1))[:, None]
+    pq = pq.astype(np.float32).astype(np.float16).astype(np.float64)  # the query as the index sees it
+    best_d, best_i = _float64_reference_topk(ix, pq, n, k, 2_000_000)
+    for j, q in enumerate(qs):
+        np.testing.assert_allclose(dist[q], best_d[j, :k], rtol=1e-5, atol=1e-5)
+        tol = 1e-5 + 1e-5 * np.abs(best_d[j])
+        gap = np.diff(best_d[j])
+        clear = np.ones(k, bool)
+        clear &= gap > 2 * tol[:k]
+        clear[1:] &= gap[:-1] > 2 * tol[1:k]
+        assert clear.sum() > k // 4  # (50M i.i.d. neighbours crowd together: fewer gaps clear the tolerance than at 5M)
+        assert np.array_equal(ids[q][clear], best_i[j, :k][clear])
+        # and as sets, up to members within the tolerance of the k-th distance
+        kth = best_d[j, k - 1]
+        sure = best_i[j, :k][best_d[j, :k] < kth - 2 * tol[k - 1]]
+        assert set(sure.tolist()) <= set(ids[q].tolist())
+    ix.close()
+
+
+def test_c4_hnsw_1m_vectors_walk_is_the_oracles(pkg, oracle):
+    """BASELINE configs[3]'s HNSW leg at size: a 1M x d = 256 graph (maxM 16, efConstruction 200, i.i.d. N(0,1) as SURVEY
+    8(d) says; built by the device builder), 64 queries at the production (k, ef) = (200, 800) and at (10, 100): ids, order
+    and float distance bits equal the oracle's walk (HnswIndex.java:538-623 restated in oracle/hnsw_oracle.c) over the
+    exported graph and the stored fp16-rounded vectors."""
+    da, hn = pkg.dense_ann, pkg.hnsw_ann
+    n, d = 1_000_000, 256
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    m = da.DistanceMetric.Cosine
+    ix = hn.Hnsw.build(m, x, max_m=16, ef_construction=200, seed=1, n_threads=16, gpu=True)
+    del x
+    graph, stored = ix.graph(), ix.stored_vectors()
+    lv, it, off, nb, entry, max_level = graph
+    assert (lv == 0).sum() == n and max_level >= 3
+    q = rng.standard_normal((64, d)).astype(np.float32)
+    pq = oracle.dense_prepare(int(m), q)
+    for k, ef in ((200, 800), (10, 100)):
+        ids, dist, cnt = ix.search(q, k, ef)
+        assert np.all(cnt == k)
+        for qi in range(len(q)):
+            o_items, o_dist, _ = oracle.hnsw_search(int(m), stored, graph, pq[qi], k, ef)
+            assert np.array_equal(ids[qi, :cnt[qi]], o_items), f"k={k} ef={ef} query {qi}: neighbours differ"
+            assert np.array_equal(dist[qi, :cnt[qi]].view(np.int32), o_dist.view(np.int32)), f"k={k} ef={ef} query {qi}: distance bits differ"
+    ix.close()
