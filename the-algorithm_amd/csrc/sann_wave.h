@@ -5,6 +5,13 @@
 
 #include <cstdint>
 
+// The lane number the helpers below branch on.  A kernel whose body is one big LOOP (sann_pipe.hip) defines it, before this
+// header is included, as something the optimiser cannot prove loop-invariant: the dozens of lane predicates of the sort
+// networks are otherwise hoisted out of the loop and held in SGPR pairs for the kernel's whole life (97 spilled SGPRs).
+#ifndef SANN_WAVE_LANE
+#define SANN_WAVE_LANE() ((int)(threadIdx.x & 63))
+#endif
+
 namespace sann {
 
 // ---------------------------------------------------------------------------------------------
@@ -40,7 +47,7 @@ __device__ inline int wave_incl_scan_i32(int x) {
 // sort below ~6k cycles of latency): quad permutes, row shifts, and gfx950's row / half-wave swaps.
 template <int J>
 __device__ inline uint32_t lane_xor(uint32_t v) {
-  const int lane = threadIdx.x & 63;
+  const int lane = SANN_WAVE_LANE();
   if constexpr (J == 1) return dpp_u32<0xB1, 0xf>(v, v);  // quad_perm [1,0,3,2]
   else if constexpr (J == 2) return dpp_u32<0x4E, 0xf>(v, v);  // quad_perm [2,3,0,1]
   else if constexpr (J == 4 || J == 8) {
@@ -57,7 +64,7 @@ __device__ inline uint32_t lane_xor(uint32_t v) {
 }
 template <int K, int J>
 __device__ inline uint32_t bitonic_step(uint32_t v) {
-  const int lane = threadIdx.x & 63;
+  const int lane = SANN_WAVE_LANE();
   const uint32_t o = lane_xor<J>(v);
   const bool keep_max = ((lane & K) == 0) == ((lane & J) == 0);
   return keep_max ? (v > o ? v : o) : (v < o ? v : o);
@@ -82,7 +89,7 @@ __device__ inline uint64_t lane_xor_u64(uint64_t v) {
 }
 template <int K, int J>
 __device__ inline void bitonic_step_k128(uint64_t &hi, uint64_t &lo) {
-  const int lane = threadIdx.x & 63;
+  const int lane = SANN_WAVE_LANE();
   const uint64_t ohi = lane_xor_u64<J>(hi), olo = lane_xor_u64<J>(lo);
   const bool keep_max = ((lane & K) == 0) == ((lane & J) == 0);
   const bool o_gt = ohi > hi || (ohi == hi && olo > lo);
