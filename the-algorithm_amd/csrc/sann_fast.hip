@@ -1117,7 +1117,6 @@ hipError_t launch_unit_fast(const IndexView &ix, const BatchView &b, const FastP
                             hipStream_t stream) {
   if (n_units <= 0) return hipSuccess;
   if (b.cap < FAST_SCAP) return hipErrorInvalidValue;
-  if (unit_pipe_serves(b, fp)) return launch_unit_pipe(ix, b, fp, stream);
   switch (fp.unit_capacity) {
     case 256: return launch_one<64, 4>(ix, b, fp, stream);
     case 512: return launch_one<128, 4>(ix, b, fp, stream);

@@ -64,10 +64,5 @@ hipError_t launch_desc(const IndexView &ix, const BatchView &b, int n_units, int
 hipError_t launch_unit_ablation(const IndexView &ix, const BatchView &b, const FastParams &fp, int abl, hipStream_t stream);
 hipError_t launch_unit_fast(const IndexView &ix, const BatchView &b, const FastParams &fp, int n_units,
                             hipStream_t stream);
-// the software-pipelined form of the same kernel (sann_pipe.hip): persistent workgroups, the next unit's postings in
-// flight while the current one is worked on; serves 256-thread geometries with <= 64 scanned clusters and no norms column
-// (SANN_PIPE=0 turns it off: every unit then runs on unit_fast_kernel)
-bool unit_pipe_serves(const BatchView &b, const FastParams &fp);
-hipError_t launch_unit_pipe(const IndexView &ix, const BatchView &b, const FastParams &fp, hipStream_t stream);
 
 }  // namespace sann

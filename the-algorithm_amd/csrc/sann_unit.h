@@ -1,6 +1,6 @@
-// sann_unit.h -- what the two forms of the (query, partition) unit kernel share (device only): the fp32 pre-filter score,
-// the cluster-level cut, the unit's candidate quota, the blocked Bloom filter's hash bits.  sann_fast.hip holds the
-// one-unit-per-workgroup kernel (every geometry), sann_pipe.hip the software-pipelined one (the benchmark's geometry).
+// sann_unit.h -- the (query, partition) unit kernel's arithmetic that does not depend on its structure (device only): the
+// fp32 pre-filter score, the cluster-level cut, the unit's candidate quota, the blocked Bloom filter's hash bits.  Used by
+// sann_fast.hip (round 3 also measured a software-pipelined kernel on top of it: profiles/r03_pipelined_unit_kernel_experiment.txt).
 #pragma once
 #include <hip/hip_runtime.h>
 

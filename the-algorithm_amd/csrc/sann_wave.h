@@ -5,9 +5,10 @@
 
 #include <cstdint>
 
-// The lane number the helpers below branch on.  A kernel whose body is one big LOOP (sann_pipe.hip) defines it, before this
-// header is included, as something the optimiser cannot prove loop-invariant: the dozens of lane predicates of the sort
-// networks are otherwise hoisted out of the loop and held in SGPR pairs for the kernel's whole life (97 spilled SGPRs).
+// The lane number the helpers below branch on.  A kernel whose body is one big LOOP can define it, before this header is
+// included, as something the optimiser cannot prove loop-invariant: the dozens of lane predicates of the sort networks are
+// otherwise hoisted out of the loop and held in SGPR pairs for the kernel's whole life (round 3's pipelined unit kernel: 97
+// spilled SGPRs; profiles/r03_pipelined_unit_kernel_experiment.txt).
 #ifndef SANN_WAVE_LANE
 #define SANN_WAVE_LANE() ((int)(threadIdx.x & 63))
 #endif

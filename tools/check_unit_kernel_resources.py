@@ -8,8 +8,6 @@ a build that spills is therefore not merely slower, it is wrong (and was: nondet
 The launch bounds and the kernel's register diet are chosen so that nothing spills; this script keeps it that way.
 
 usage: check_unit_kernel_resources.py <stderr of hipcc -Rpass-analysis=kernel-resource-usage> [kernel name, default unit_fast_kernel]
-(sann_pipe.hip's unit_pipe_kernel keeps loads in flight in registers across most of its body: a spill of one of those
-registers would store a value that has not arrived yet.  Same gate.)
 """
 import re
 import sys
