@@ -84,6 +84,11 @@ def main():
                          "and out (N = 1 only; -1 = as many as --steps, 0 = skip)")
     ap.add_argument("--e2e-threads", type=int, default=4, help="concurrent callers of the end-to-end leg (the reference's callers are Finagle worker threads)")
     ap.add_argument("--e2e-query-sets", type=int, default=4, help="distinct query batches the end-to-end leg rotates through")
+    ap.add_argument("--mb-threads", type=int, default=512, help="caller threads of the micro-batched leg (0 = skip)")
+    ap.add_argument("--mb-requests", type=int, default=65536, help="single requests of the micro-batched leg, all threads together")
+    ap.add_argument("--mb-batch", type=int, default=512, help="max_batch of the micro-batching queue in that leg")
+    ap.add_argument("--mb-wait-us", type=int, default=200, help="max_wait_us of the micro-batching queue in that leg")
+    ap.add_argument("--mb-dispatchers", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cpu_count, 16))")
     args = ap.parse_args()
     if args.workload != "sann":
@@ -477,6 +482,38 @@ def main():
                        "preparation, descriptor + unit + merge kernels, D2H of ids/scores/counts into pinned host arrays; "
                        "pooled batch objects, no allocation in steady state"}
 
+    # ---- micro-batched leg: SINGLE requests from many native caller threads through the micro-batching queue ----------
+    # (the reference's calling pattern: one getTweetCandidates per Finagle worker thread at a time,
+    # SimClustersANNCandidateSource.scala:77-94).  tools/micro/batcher_load.c drives sann_batcher_get_tweet_candidates from
+    # pthreads; Python only sets it up.  Reported beside `value`, never instead of it.
+    mb_leg = None
+    load_so = os.path.join(ROOT, "tools", "micro", "libbatcher_load.so")
+    if not sharded and n_e2e > 0 and args.mb_threads > 0 and os.path.exists(load_so):
+        load = ctypes.CDLL(load_so)
+        load.batcher_load_run.restype = ctypes.c_int
+        load.batcher_load_run.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)]
+        mb = pkg.MicroBatcher(index, max_batch=args.mb_batch, max_wait_us=args.mb_wait_us, n_dispatchers=args.mb_dispatchers)
+        cfg_c = cfg.to_c()
+        o_q, c_q, s_q = (np.ascontiguousarray(qsets[0][0], np.int64), np.ascontiguousarray(qsets[0][1], np.int32),
+                         np.ascontiguousarray(qsets[0][2], np.float64))
+        res = (ctypes.c_double * 6)()
+        per = max(8, args.mb_requests // args.mb_threads)
+        for n_req in (max(2, per // 8), per):  # a short warm-up run, then the measured one
+            rc = load.batcher_load_run(mb._h, args.mb_threads, n_req, nq, o_q.ctypes.data, c_q.ctypes.data, s_q.ctypes.data,
+                                       ctypes.byref(cfg_c), now_ms, res)
+            assert rc == 0, lib.sann_last_error()
+        st_mb = mb.stats()
+        mb.close()
+        mb_leg = {"value": res[2] / res[0], "unit": "candidates/sec", "requests_per_sec": res[1] / res[0], "requests": int(res[1]),
+                  "caller_threads": args.mb_threads, "latency_us_p50": res[3], "latency_us_p99": res[4], "latency_us_max": res[5],
+                  "max_batch": args.mb_batch, "max_wait_us": args.mb_wait_us, "dispatchers": args.mb_dispatchers,
+                  "mean_batch": st_mb.n_requests / max(st_mb.n_batches, 1), "batches_closed_full": int(st_mb.n_closed_full),
+                  "batches_closed_by_deadline": int(st_mb.n_closed_by_deadline),
+                  "what": "one blocking sann_batcher_get_tweet_candidates per caller thread at a time (native pthreads, "
+                          "tools/micro/batcher_load.c), folded into batches by the library's micro-batching queue; every request "
+                          "pays its copy into the open batch, the batch's whole boundary call and the copy of its rows"}
+
     if rank != 0:
         if sharded:
             dist.barrier()
@@ -590,6 +627,7 @@ def main():
         "sharded_equals_unsharded": check_sharded_against_unsharded() if world > 1 else None,
         "roofline": roof,
         "end_to_end": e2e,
+        "micro_batched": mb_leg,
         "cpu_baseline": cpu,
         "corpus_build_s": t_corpus,
     }

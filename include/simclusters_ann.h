@@ -338,6 +338,57 @@ int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_
                               int64_t *out_ids, double *out_scores, int32_t out_stride, int32_t *out_counts,
                               int32_t *out_map_sizes);
 
+/* The same with one Time.now PER QUERY (now_ms[nq]): requests that were collected into one batch over a fraction of a
+ * millisecond keep the age window (ApproximateCosineSimilarity.scala:65-72) each of them would have had alone. */
+int sann_get_tweet_candidates_at(sann_index_t *index, int32_t variant, const int64_t *now_ms, int32_t nq,
+                                 const int64_t *emb_offsets, const int32_t *emb_cluster_ids,
+                                 const double *emb_scores, const int64_t *source_tweet_ids,
+                                 const uint8_t *has_source_tweet, const sann_config_t *configs,
+                                 int32_t n_configs, const int64_t *scan_offsets, const int32_t *scan_cluster_ids,
+                                 int64_t *out_ids, double *out_scores, int32_t out_stride, int32_t *out_counts,
+                                 int32_t *out_map_sizes);
+
+/*
+ * The micro-batching queue (SURVEY 8(b) "Threading"): the reference calls the operator once per REQUEST, from many Finagle
+ * worker threads (SimClustersANNCandidateSource.scala:77-94, 40 ms budget: modules/FlagsModule.scala:8-12); the GPU wants
+ * ~1000 requests per launch.  sann_submit copies one request into the open batch and returns a ticket; a batch closes when
+ * it holds max_batch requests or max_wait_us after its first request; dispatcher threads (each with a pooled batch object
+ * and a HIP stream of its own) run closed batches through sann_get_tweet_candidates_at -- every request with ITS now_ms --
+ * and hand each request its rows; sann_wait / sann_poll collect.  A request's answer is bit for bit what
+ * sann_get_tweet_candidates returns for it alone.  Requests take fetchCandidates' default cluster selection (explicit scan
+ * keys stay with the batch calls).  All functions are thread-safe.
+ */
+typedef struct sann_batcher sann_batcher_t;
+typedef struct sann_batcher_options {
+  int32_t variant;        /* SANN_VARIANT_*, one per queue (the service picks it by flag at start-up) */
+  int32_t max_batch;      /* requests per batch; 0 = 1024 */
+  int32_t max_wait_us;    /* a batch leaves at the latest this long after its first request; 0 = 500 */
+  int32_t n_dispatchers;  /* batches in flight; 0 = 3 */
+} sann_batcher_options_t;
+typedef struct sann_batcher_stats {
+  int64_t n_requests, n_batches, n_closed_full, n_closed_by_deadline, max_batch;
+} sann_batcher_stats_t;
+int sann_batcher_create(sann_index_t *index, const sann_batcher_options_t *options /* NULL = defaults, original variant */,
+                        sann_batcher_t **out);
+/* Runs whatever was submitted, then stops the dispatchers.  Tickets nobody collected are dropped. */
+int sann_batcher_destroy(sann_batcher_t *batcher);
+/* One getTweetCandidates request.  cluster_ids / scores: the source embedding (copied: reusable on return).  The out arrays
+ * are the caller's and must stay valid until the ticket is collected; out_capacity >= min(maxNumResults, 1000).
+ * Rows come sorted (score descending, tweet id ascending); *out_map_size is candidateScoresMap.size. */
+int sann_submit(sann_batcher_t *batcher, int64_t now_ms, int32_t n_embedding, const int32_t *cluster_ids, const double *scores,
+                int64_t source_tweet_id, int32_t has_source_tweet, const sann_config_t *config, int32_t out_capacity,
+                int64_t *out_ids, double *out_scores, int32_t *out_count, int32_t *out_map_size, int64_t *ticket);
+/* Block until the request is answered; returns ITS status (and sets this thread's sann_last_error).  A ticket is collected once. */
+int sann_wait(sann_batcher_t *batcher, int64_t ticket);
+/* *done = 1 and the ticket is collected (status returned) when the answer is there, else *done = 0. */
+int sann_poll(sann_batcher_t *batcher, int64_t ticket, int32_t *done);
+/* sann_submit + sann_wait: the shape of ApproximateCosineSimilarity.apply for one request. */
+int sann_batcher_get_tweet_candidates(sann_batcher_t *batcher, int64_t now_ms, int32_t n_embedding, const int32_t *cluster_ids,
+                                      const double *scores, int64_t source_tweet_id, int32_t has_source_tweet,
+                                      const sann_config_t *config, int32_t out_capacity, int64_t *out_ids, double *out_scores,
+                                      int32_t *out_count, int32_t *out_map_size);
+int sann_batcher_stats(sann_batcher_t *batcher, sann_batcher_stats_t *stats);
+
 /* Pinned (page-locked) host memory for request / response buffers a shim keeps across calls (e.g. behind a direct
  * ByteBuffer): device copies to and from it run at PCIe speed instead of being staged through the runtime. */
 int sann_host_alloc(int64_t bytes, void **out);

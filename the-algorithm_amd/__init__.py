@@ -10,6 +10,7 @@ from .simclusters_ann import (  # noqa: F401
     ClusterTweetIndex,
     LegacySimClustersANNCandidateSource,
     LegacySimClustersANNConfig,
+    MicroBatcher,
     QueryBatch,
     ScoringAlgorithm,
     SimClustersANNConfig,

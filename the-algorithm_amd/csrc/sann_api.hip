@@ -243,8 +243,8 @@ struct sann_batch {
   DevBuf d_stage;
   struct StageLayout {
     size_t emb_offsets = 0, src_ids = 0, scan_offsets = 0, emb_scores = 0, emb_cids = 0, scan_cids = 0, configs = 0,
-           scan_begin = 0, has_src = 0, bytes = 0;
-    bool has_scan = false, has_sources = false;
+           scan_begin = 0, has_src = 0, now_q = 0, bytes = 0;
+    bool has_scan = false, has_sources = false, has_now_q = false;
     int32_t n_configs = 0;
   } lay;
   // ---- host-prepared form (host path only)
@@ -280,6 +280,7 @@ struct sann_batch {
   FastParams fast{};
   sann_batch_stats_t stats{};
   bool ran = false;
+  bool slow_tail_ran = false;  // the last sann_batch_finish re-ran units on the general path (results changed after the first merge)
   hipStream_t own_stream = nullptr;  // pooled batches (sann_get_tweet_candidates) run on a stream of their own
   // optional HIP-event timing of the kernels, on the stream they are launched on
   bool profiling = false;
@@ -541,7 +542,7 @@ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const int64_t *emb_offsets,
                 const int32_t *emb_cluster_ids, const double *emb_scores, const int64_t *source_tweet_ids,
                 const uint8_t *has_source_tweet, const sann_config_t *configs, int32_t n_configs,
-                const int64_t *scan_offsets, const int32_t *scan_cluster_ids) {
+                const int64_t *scan_offsets, const int32_t *scan_cluster_ids, const int64_t *now_ms_q = nullptr) {
   sann_index *ix = b->ix;
   const int variant = b->variant;
   if (nq < 0) return fail(SANN_EINVAL, "nq < 0");
@@ -584,6 +585,7 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
   sann_batch::StageLayout L;
   L.has_scan = has_scan;
   L.has_sources = has_sources;
+  L.has_now_q = now_ms_q != nullptr && nq > 0;
   L.n_configs = n_configs;
   const int64_t e0 = nq ? emb_offsets[0] : 0, e1 = nq ? emb_offsets[nq] : 0;
   const int64_t s0 = (nq && has_scan) ? scan_offsets[0] : 0, s1 = (nq && has_scan) ? scan_offsets[nq] : 0;
@@ -600,6 +602,7 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
     L.configs = o; o = align16(o + (size_t)n_configs * sizeof(sann_config_t));
     L.scan_begin = o; o = align16(o + (size_t)nq * 4);
     L.has_src = o; o = align16(o + (has_sources ? (size_t)nq : 0));
+    L.now_q = o; o = align16(o + (now_ms_q ? (size_t)nq * 8 : 0));
     L.bytes = o;
   }
   HIP_TRY(b->stage.reserve(std::max<size_t>(L.bytes, 16)));
@@ -671,6 +674,7 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
       memcpy(S + L.src_ids, source_tweet_ids, (size_t)nq * 8);
       memcpy(S + L.has_src, has_source_tweet, (size_t)nq);
     }
+    if (L.has_now_q) memcpy(S + L.now_q, now_ms_q, (size_t)nq * 8);
   }
 
   // ---- device buffers (kept between resets; they only grow) -------------------------------------------------------
@@ -773,6 +777,7 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
       pv.scan_w = b->scan_w.as<double>();
       pv.d_k = b->d_k.as<int32_t>();
       pv.now_ms = now_ms;
+      pv.now_ms_q = L.has_now_q ? b->d_staged<int64_t>(L.now_q) : nullptr;
       pv.n_rows = (int32_t)ix->cluster_ids.size();
       pv.n_configs = n_configs;
       pv.variant = variant;
@@ -797,7 +802,7 @@ int batch_reset(sann_batch *b, hipStream_t st, int64_t now_ms, int32_t nq, const
   for (int32_t q = 0; q < nq; q++) {
     const sann_config_t &cfg = configs[n_configs == 1 ? 0 : q];
     const bool has_src = has_sources && has_source_tweet[q];
-    int rc = prepare_query_host(ix, variant, now_ms, cfg, emb_cluster_ids + emb_offsets[q], emb_scores + emb_offsets[q],
+    int rc = prepare_query_host(ix, variant, now_ms_q ? now_ms_q[q] : now_ms, cfg, emb_cluster_ids + emb_offsets[q], emb_scores + emb_offsets[q],
                                 emb_offsets[q + 1] - emb_offsets[q], has_src, has_src ? source_tweet_ids[q] : 0,
                                 has_scan ? scan_cluster_ids + scan_offsets[q] : nullptr,
                                 has_scan ? scan_offsets[q + 1] - scan_offsets[q] : -1, hq, emb, by_id, keys);
@@ -918,7 +923,7 @@ int ensure_unit_bounds(sann_batch *b, const std::vector<int32_t> &queries) {
   HostQuery hq;
   for (int32_t q : queries) {
     const bool has_src = L.has_sources && has[q];
-    int rc = prepare_query_host(b->ix, b->variant, b->now_ms, cfgs[L.n_configs == 1 ? 0 : q], ec + eo[q], es + eo[q],
+    int rc = prepare_query_host(b->ix, b->variant, L.has_now_q ? b->staged<int64_t>(L.now_q)[q] : b->now_ms, cfgs[L.n_configs == 1 ? 0 : q], ec + eo[q], es + eo[q],
                                 eo[q + 1] - eo[q], has_src, has_src ? src[q] : 0, L.has_scan ? sc + so[q] : nullptr,
                                 L.has_scan ? so[q + 1] - so[q] : -1, hq, emb, by_id, keys);
     if (rc != SANN_OK) return rc;
@@ -1119,7 +1124,9 @@ int sann_batch_finish(sann_batch_t *b, void *hip_stream) try {
     b->qstat_pending = false;
   }
   const int n_over = b->h_status[0], n_inexact = b->h_status[1];
+  b->slow_tail_ran = false;
   if (n_over == 0 && n_inexact == 0) return SANN_OK;
+  b->slow_tail_ran = true;
   if (!b->use_fast) return fail(SANN_EINTERNAL, "general path reported overflow/inexact units");
 
   // ---- slow tail: re-run on the general path whatever the fast path could not settle ---------
@@ -1152,8 +1159,9 @@ int sann_batch_finish(sann_batch_t *b, void *hip_stream) try {
   return SANN_OK;
 } ABI_CATCH
 
+// enqueue the copies of a batch's results to the host on `st` (sync = false: the caller synchronises the stream)
 static int results_impl(sann_batch_t *b, hipStream_t st, int64_t *out_ids, double *out_scores, int32_t out_stride,
-                        int32_t *out_counts, int32_t *out_map_sizes) {
+                        int32_t *out_counts, int32_t *out_map_sizes, bool sync = true) {
   if (b->nq == 0) return SANN_OK;
   if (out_stride < b->stride) return fail(SANN_EINVAL, "out_stride smaller than the batch's max k");
   if (b->bound_chunk_q > 0) return fail(SANN_EINVAL, "outputs are bound to caller-owned chunked buffers");
@@ -1172,7 +1180,7 @@ static int results_impl(sann_batch_t *b, hipStream_t st, int64_t *out_ids, doubl
   }
   if (out_counts) HIP_TRY(hipMemcpyAsync(out_counts, bv.out_counts, (size_t)b->nq * 4, hipMemcpyDeviceToHost, st));
   if (out_map_sizes) HIP_TRY(hipMemcpyAsync(out_map_sizes, bv.out_map_sizes, (size_t)b->nq * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  if (sync) HIP_TRY(hipStreamSynchronize(st));
   return SANN_OK;
 }
 
@@ -1435,12 +1443,13 @@ int sann_batch_destroy(sann_batch_t *b) try {
 // One call = (pooled batch) reset + run + finish + results: the shape a JNI stub binds.  Every concurrent caller works on
 // a batch object of its own, taken from the index's pool and given back afterwards, on that object's own non-blocking
 // stream: after the first few calls nothing is allocated, and callers on different threads overlap on the GPU.
-int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_ms, int32_t nq,
-                              const int64_t *emb_offsets, const int32_t *emb_cluster_ids, const double *emb_scores,
-                              const int64_t *source_tweet_ids, const uint8_t *has_source_tweet,
-                              const sann_config_t *configs, int32_t n_configs, const int64_t *scan_offsets,
-                              const int32_t *scan_cluster_ids, int64_t *out_ids, double *out_scores,
-                              int32_t out_stride, int32_t *out_counts, int32_t *out_map_sizes) try {
+}  // extern "C"
+int sann_candidates_pooled(sann_index_t *index, int32_t variant, int64_t now_ms, const int64_t *now_ms_q, int32_t nq,
+                           const int64_t *emb_offsets, const int32_t *emb_cluster_ids, const double *emb_scores,
+                           const int64_t *source_tweet_ids, const uint8_t *has_source_tweet,
+                           const sann_config_t *configs, int32_t n_configs, const int64_t *scan_offsets,
+                           const int32_t *scan_cluster_ids, int64_t *out_ids, double *out_scores,
+                           int32_t out_stride, int32_t *out_counts, int32_t *out_map_sizes) {
   if (!index) return fail(SANN_EINVAL, "index is NULL");
   if (variant < 0 || variant > 3) return fail(SANN_EINVAL, "unknown variant");
   sann_batch *b = nullptr;
@@ -1465,10 +1474,15 @@ int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_
   b->variant = variant;
   hipStream_t st = b->own_stream;
   int rc = batch_reset(b, st, now_ms, nq, emb_offsets, emb_cluster_ids, emb_scores, source_tweet_ids, has_source_tweet,
-                       configs, n_configs, scan_offsets, scan_cluster_ids);
+                       configs, n_configs, scan_offsets, scan_cluster_ids, now_ms_q);
   if (rc == SANN_OK) rc = sann_batch_run(b, st);
+  // The answer goes home right behind the merge kernel, on the same stream, BEFORE the host has looked at the batch's status:
+  // the copy engine starts the moment the kernels end, and the call has one host round trip (finish) instead of two.  In the
+  // rare batch whose finish re-runs units on the general path the rows are copied again.
+  if (rc == SANN_OK && out_stride >= b->stride) rc = results_impl(b, st, out_ids, out_scores, out_stride, out_counts, out_map_sizes, false);
   if (rc == SANN_OK) rc = sann_batch_finish(b, st);
-  if (rc == SANN_OK) rc = results_impl(b, st, out_ids, out_scores, out_stride, out_counts, out_map_sizes);
+  if (rc == SANN_OK && (b->slow_tail_ran || out_stride < b->stride))
+    rc = results_impl(b, st, out_ids, out_scores, out_stride, out_counts, out_map_sizes);
   std::string keep = g_err;
   bool pooled = false;
   if (rc == SANN_OK || rc == SANN_EINVAL || rc == SANN_ELIMIT) {  // a device error may have left the object in an unknown state
@@ -1485,6 +1499,30 @@ int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_
   }
   if (rc != SANN_OK) g_err = keep;
   return rc;
+}
+extern "C" {
+
+int sann_get_tweet_candidates(sann_index_t *index, int32_t variant, int64_t now_ms, int32_t nq,
+                              const int64_t *emb_offsets, const int32_t *emb_cluster_ids, const double *emb_scores,
+                              const int64_t *source_tweet_ids, const uint8_t *has_source_tweet,
+                              const sann_config_t *configs, int32_t n_configs, const int64_t *scan_offsets,
+                              const int32_t *scan_cluster_ids, int64_t *out_ids, double *out_scores,
+                              int32_t out_stride, int32_t *out_counts, int32_t *out_map_sizes) try {
+  return sann_candidates_pooled(index, variant, now_ms, nullptr, nq, emb_offsets, emb_cluster_ids, emb_scores, source_tweet_ids,
+                                has_source_tweet, configs, n_configs, scan_offsets, scan_cluster_ids, out_ids, out_scores,
+                                out_stride, out_counts, out_map_sizes);
+} ABI_CATCH
+
+int sann_get_tweet_candidates_at(sann_index_t *index, int32_t variant, const int64_t *now_ms, int32_t nq,
+                                 const int64_t *emb_offsets, const int32_t *emb_cluster_ids, const double *emb_scores,
+                                 const int64_t *source_tweet_ids, const uint8_t *has_source_tweet,
+                                 const sann_config_t *configs, int32_t n_configs, const int64_t *scan_offsets,
+                                 const int32_t *scan_cluster_ids, int64_t *out_ids, double *out_scores,
+                                 int32_t out_stride, int32_t *out_counts, int32_t *out_map_sizes) try {
+  if (nq > 0 && !now_ms) return fail(SANN_EINVAL, "now_ms is NULL");
+  return sann_candidates_pooled(index, variant, nq > 0 ? now_ms[0] : 0, now_ms, nq, emb_offsets, emb_cluster_ids, emb_scores,
+                                source_tweet_ids, has_source_tweet, configs, n_configs, scan_offsets, scan_cluster_ids, out_ids,
+                                out_scores, out_stride, out_counts, out_map_sizes);
 } ABI_CATCH
 
 int sann_host_alloc(int64_t bytes, void **out) try {

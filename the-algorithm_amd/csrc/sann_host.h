@@ -55,6 +55,14 @@ struct DevBuf {
 
 }  // namespace sann_host
 
+// sann_get_tweet_candidates[_at] behind the ABI guard (sann_api.hip): one pooled batch object per concurrent caller; now_ms_q =
+// per-query Time.now or NULL.  Also what the micro-batcher's dispatchers call (sann_batcher.hip).
+int sann_candidates_pooled(sann_index_t *index, int32_t variant, int64_t now_ms, const int64_t *now_ms_q, int32_t nq,
+                           const int64_t *emb_offsets, const int32_t *emb_cluster_ids, const double *emb_scores,
+                           const int64_t *source_tweet_ids, const uint8_t *has_source_tweet, const sann_config_t *configs,
+                           int32_t n_configs, const int64_t *scan_offsets, const int32_t *scan_cluster_ids, int64_t *out_ids,
+                           double *out_scores, int32_t out_stride, int32_t *out_counts, int32_t *out_map_sizes);
+
 struct sann_index {
   int device = 0;
   int P = 1, log2P = 0, shard_id = 0, n_shards = 1;

@@ -38,6 +38,7 @@ struct PrepView {
   double *scan_w;
   int32_t *d_k;
   int64_t now_ms;
+  const int64_t *now_ms_q;          // [nq] per-query Time.now, or NULL (every query at now_ms)
   int32_t n_rows, n_configs, variant, nq;
 };
 hipError_t launch_prep(const PrepView &in, hipStream_t stream);

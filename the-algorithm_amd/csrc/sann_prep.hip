@@ -217,10 +217,11 @@ __global__ __launch_bounds__(PWG) void prep_kernel(PrepView in) {
     h.alg = cfg.ann_algorithm;
     h.use_norms = 0;
     h.reserved = 0;
+    const int64_t now_ms = in.now_ms_q ? in.now_ms_q[q] : in.now_ms;  // Time.now of THIS request (micro-batched requests keep their own)
     h.earliest = (cfg.max_tweet_candidate_age_hours >= 175200 && !legacy)
                      ? 0
-                     : first_id_for(in.now_ms - (int64_t)cfg.max_tweet_candidate_age_hours * 3600000ll);
-    h.latest = first_id_for(in.now_ms - (int64_t)cfg.min_tweet_candidate_age_hours * 3600000ll);
+                     : first_id_for(now_ms - (int64_t)cfg.max_tweet_candidate_age_hours * 3600000ll);
+    h.latest = first_id_for(now_ms - (int64_t)cfg.min_tweet_candidate_age_hours * 3600000ll);
     if (cfg.ann_algorithm == SANN_ALG_OFFLINE_LOG_COSINE || cfg.ann_algorithm == SANN_ALG_OFFLINE_COSINE) {
       // tweets_ann.sql:44-52 (see prepare_query_host)
       h.alg = cfg.ann_algorithm == SANN_ALG_OFFLINE_LOG_COSINE ? SANN_ALG_LOG_COSINE : SANN_ALG_COSINE_NO_SOURCE_NORM;

@@ -187,6 +187,14 @@ _PROTOS = {
     "sann_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "sann_batch_destroy": (C.c_int, [C.c_void_p]),
     "sann_get_tweet_candidates": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sann_get_tweet_candidates_at": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sann_batcher_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "sann_batcher_destroy": (C.c_int, [C.c_void_p]),
+    "sann_submit": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "sann_wait": (C.c_int, [C.c_void_p, C.c_int64]),
+    "sann_poll": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
+    "sann_batcher_get_tweet_candidates": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sann_batcher_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sann_debug_normalise": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
     "sann_debug_wave_sort": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p]),
     "sann_debug_approx": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
@@ -573,7 +581,73 @@ def pinned_array(shape, dtype) -> np.ndarray:
     return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 
-def get_tweet_candidates(index: ClusterTweetIndex, emb_offsets, emb_cluster_ids, emb_scores, configs, *, now_ms: int,
+class sann_batcher_options_t(C.Structure):
+    _fields_ = [("variant", C.c_int32), ("max_batch", C.c_int32), ("max_wait_us", C.c_int32), ("n_dispatchers", C.c_int32)]
+
+
+class sann_batcher_stats_t(C.Structure):
+    _fields_ = [("n_requests", C.c_int64), ("n_batches", C.c_int64), ("n_closed_full", C.c_int64),
+                ("n_closed_by_deadline", C.c_int64), ("max_batch", C.c_int64)]
+
+
+class MicroBatcher:
+    """sann_batcher_t: the native micro-batching queue.  One request per call, from any number of threads -- the reference's
+    calling pattern (SimClustersANNCandidateSource.scala:77-94) -- folded into batches for the GPU."""
+
+    def __init__(self, index: ClusterTweetIndex, *, variant: Variant = Variant.original, max_batch: int = 0, max_wait_us: int = 0,
+                 n_dispatchers: int = 0):
+        self.index = index
+        o = sann_batcher_options_t(int(variant), max_batch, max_wait_us, n_dispatchers)
+        h = C.c_void_p()
+        _check(load_library().sann_batcher_create(index.handle, C.byref(o), C.byref(h)))
+        self._h = h
+
+    def submit(self, cluster_ids, scores, config: "SimClustersANNConfig", *, now_ms: int, source_tweet_id: Optional[int] = None):
+        """-> (ticket, (ids, scores, count, map_size)): the arrays are filled when wait(ticket) has returned."""
+        cc = np.ascontiguousarray(cluster_ids, np.int32)
+        ss = np.ascontiguousarray(scores, np.float64)
+        cap = max(1, min(max(config.maxNumResults, 0), 1000))
+        out = (np.zeros(cap, np.int64), np.zeros(cap, np.float64), np.zeros(1, np.int32), np.zeros(1, np.int32))
+        cfg = config.to_c()
+        t = C.c_int64()
+        _check(load_library().sann_submit(self._h, int(now_ms), len(cc), _ptr(cc), _ptr(ss), int(source_tweet_id or 0),
+                                          0 if source_tweet_id is None else 1, C.byref(cfg), cap, _ptr(out[0]), _ptr(out[1]),
+                                          _ptr(out[2]), _ptr(out[3]), C.byref(t)))
+        return t.value, out
+
+    def wait(self, ticket: int):
+        _check(load_library().sann_wait(self._h, ticket))
+
+    def poll(self, ticket: int) -> bool:
+        d = C.c_int32()
+        _check(load_library().sann_poll(self._h, ticket, C.byref(d)))
+        return bool(d.value)
+
+    def get_tweet_candidates(self, cluster_ids, scores, config, *, now_ms: int, source_tweet_id: Optional[int] = None):
+        """One request, blocking: (ids, scores, map_size) as ApproximateCosineSimilarity.apply would return them."""
+        t, out = self.submit(cluster_ids, scores, config, now_ms=now_ms, source_tweet_id=source_tweet_id)
+        self.wait(t)
+        n = int(out[2][0])
+        return out[0][:n], out[1][:n], int(out[3][0])
+
+    def stats(self) -> sann_batcher_stats_t:
+        st = sann_batcher_stats_t()
+        _check(load_library().sann_batcher_stats(self._h, C.byref(st)))
+        return st
+
+    def close(self):
+        if self._h:
+            load_library().sann_batcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def get_tweet_candidates(index: ClusterTweetIndex, emb_offsets, emb_cluster_ids, emb_scores, configs, *, now_ms,
                          variant: Variant = Variant.original, source_tweet_ids=None, has_source_tweet=None,
                          scan_offsets=None, scan_cluster_ids=None, out=None):
     """sann_get_tweet_candidates: host arrays in, host arrays out, one call (what the JNI stub of INTEGRATION.md
@@ -597,9 +671,16 @@ def get_tweet_candidates(index: ClusterTweetIndex, emb_offsets, emb_cluster_ids,
         out = (np.zeros((nq, stride), np.int64), np.zeros((nq, stride), np.float64), np.zeros(nq, np.int32), np.zeros(nq, np.int32))
     ids, scores, counts, msz = out
     assert ids.shape[0] >= nq and ids.shape[1] >= stride and ids.shape == scores.shape
-    _check(lib.sann_get_tweet_candidates(index.handle, int(variant), int(now_ms), nq, _ptr(eo), _ptr(ec), _ptr(es), _ptr(src),
-                                         _ptr(has), C.cast(carr, C.c_void_p), len(configs), _ptr(so), _ptr(sc), _ptr(ids),
-                                         _ptr(scores), ids.shape[1], _ptr(counts), _ptr(msz)))
+    if np.ndim(now_ms) == 0:
+        _check(lib.sann_get_tweet_candidates(index.handle, int(variant), int(now_ms), nq, _ptr(eo), _ptr(ec), _ptr(es), _ptr(src),
+                                             _ptr(has), C.cast(carr, C.c_void_p), len(configs), _ptr(so), _ptr(sc), _ptr(ids),
+                                             _ptr(scores), ids.shape[1], _ptr(counts), _ptr(msz)))
+    else:  # one Time.now per query
+        nows = np.ascontiguousarray(now_ms, np.int64)
+        assert len(nows) == nq
+        _check(lib.sann_get_tweet_candidates_at(index.handle, int(variant), _ptr(nows), nq, _ptr(eo), _ptr(ec), _ptr(es), _ptr(src),
+                                                _ptr(has), C.cast(carr, C.c_void_p), len(configs), _ptr(so), _ptr(sc), _ptr(ids),
+                                                _ptr(scores), ids.shape[1], _ptr(counts), _ptr(msz)))
     return out
 
 
