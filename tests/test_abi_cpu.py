@@ -79,19 +79,27 @@ def test_missing_library_fails_loudly(pkg, tmp_path):
 
 def test_jni_glue_compiles_against_the_minimal_jni_header():
     """the JNI glue of INTEGRATION.md is real C, compile-checked against a hand-declared JNI
-    subset (no JDK in this image) and link-checked against the library: every C-ABI symbol it calls exists."""
+    subset (no JDK in this image) and link-checked against the library: every C-ABI symbol it calls exists.  All three
+    services' glue files (tests/test_jni_cpu.py and test_jni_gpu.py also EXECUTE them through a hand-made JNIEnv)."""
     import subprocess, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     jni = os.path.join(root, "the-algorithm_amd", "jni")
-    src = os.path.join(jni, "simclusters_ann_jni.c")
-    subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-DSANN_JNI_MINIMAL", "-I", jni, src], check=True)
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "libsimclusters_ann_jni.so")
-        subprocess.run(["gcc", "-shared", "-fPIC", "-DSANN_JNI_MINIMAL", "-I", jni, src, "-o", out, "-L", os.path.join(root, "the-algorithm_amd"),
-                        "-lsimclusters_amd", "-Wl,--no-undefined", "-Wl,--allow-shlib-undefined"], check=True)
-        syms = subprocess.run(["nm", "-D", "--defined-only", out], check=True, capture_output=True, text=True).stdout
-        for name in ("indexBuild", "indexDestroy", "hostAlloc", "hostFree", "getTweetCandidates0"):
-            assert f"Java_com_twitter_simclustersann_gpu_SannJni_{name}" in syms
+    want = {
+        "simclusters_ann_jni.c": ("com_twitter_simclustersann_gpu_SannJni", ("indexBuild", "indexDestroy", "hostAlloc", "hostFree", "getTweetCandidates0")),
+        "representation_scorer_jni.c": ("com_twitter_representationscorer_gpu_RsxJni", ("storeBuild", "storeDestroy", "pairScores", "listScores")),
+        "ann_jni.c": ("com_twitter_ann_gpu_AnnJni", ("denseIndexBuild", "denseIndexDestroy", "denseSearch", "hnswIndexBuildInsert",
+                                                     "hnswIndexLoadDirectory", "hnswIndexDestroy", "hnswSearch")),
+    }
+    for fname, (cls, names) in want.items():
+        src = os.path.join(jni, fname)
+        subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-DSANN_JNI_MINIMAL", "-I", jni, src], check=True)
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "lib" + fname[:-2] + ".so")
+            subprocess.run(["gcc", "-shared", "-fPIC", "-DSANN_JNI_MINIMAL", "-I", jni, src, "-o", out, "-L", os.path.join(root, "the-algorithm_amd"),
+                            "-lsimclusters_amd", "-Wl,--no-undefined", "-Wl,--allow-shlib-undefined"], check=True)
+            syms = subprocess.run(["nm", "-D", "--defined-only", out], check=True, capture_output=True, text=True).stdout
+            for name in names:
+                assert f"Java_{cls}_{name}" in syms
 
 
 def test_the_process_not_the_library_sets_the_hardware_queue_count(pkg):

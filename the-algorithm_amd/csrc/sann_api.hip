@@ -1476,13 +1476,12 @@ int sann_candidates_pooled(sann_index_t *index, int32_t variant, int64_t now_ms,
   int rc = batch_reset(b, st, now_ms, nq, emb_offsets, emb_cluster_ids, emb_scores, source_tweet_ids, has_source_tweet,
                        configs, n_configs, scan_offsets, scan_cluster_ids, now_ms_q);
   if (rc == SANN_OK) rc = sann_batch_run(b, st);
-  // The answer goes home right behind the merge kernel, on the same stream, BEFORE the host has looked at the batch's status:
-  // the copy engine starts the moment the kernels end, and the call has one host round trip (finish) instead of two.  In the
-  // rare batch whose finish re-runs units on the general path the rows are copied again.
-  if (rc == SANN_OK && out_stride >= b->stride) rc = results_impl(b, st, out_ids, out_scores, out_stride, out_counts, out_map_sizes, false);
+  // (Round 3 tried to enqueue the copies of the answer right behind the merge kernel, before the host has looked at the batch's
+  // status -- one host round trip per call instead of two.  With several callers it ran 3.5 x SLOWER, 1.16 ms instead of 0.33 ms
+  // per 1024-query call with four callers: a copy that waits for its own stream's kernels sits in the copy engine's queue in
+  // front of the other callers' copies.  The copies are enqueued when the kernels have finished.)
   if (rc == SANN_OK) rc = sann_batch_finish(b, st);
-  if (rc == SANN_OK && (b->slow_tail_ran || out_stride < b->stride))
-    rc = results_impl(b, st, out_ids, out_scores, out_stride, out_counts, out_map_sizes);
+  if (rc == SANN_OK) rc = results_impl(b, st, out_ids, out_scores, out_stride, out_counts, out_map_sizes);
   std::string keep = g_err;
   bool pooled = false;
   if (rc == SANN_OK || rc == SANN_EINVAL || rc == SANN_ELIMIT) {  // a device error may have left the object in an unknown state

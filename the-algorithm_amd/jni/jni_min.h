@@ -1,5 +1,5 @@
 /*
- * jni_min.h -- the subset of the Java Native Interface that simclusters_ann_jni.c uses, declared by hand so that
+ * jni_min.h -- the subset of the Java Native Interface that the glue files of this directory use, declared by hand so that
  * the glue can be COMPILE-CHECKED in an image without a JDK (tests/test_abi_cpu.py runs `gcc -fsyntax-only`).
  * Types and function names follow the JNI specification (jni.h of any JDK >= 8); the function table below lists only
  * the entries the glue calls, so it is NOT layout-compatible with the real JNINativeInterface_: a deployment build
@@ -12,6 +12,8 @@
 typedef int32_t jint;
 typedef int64_t jlong;
 typedef double jdouble;
+typedef float jfloat;
+typedef int8_t jbyte;
 typedef uint8_t jboolean;
 typedef jint jsize;
 struct _jobject;
@@ -23,6 +25,8 @@ typedef jobject jarray;
 typedef jarray jintArray;
 typedef jarray jlongArray;
 typedef jarray jdoubleArray;
+typedef jarray jfloatArray;
+typedef jarray jbyteArray;
 
 #define JNIEXPORT __attribute__((visibility("default")))
 #define JNICALL
@@ -39,5 +43,7 @@ struct JNINativeInterface_ {
   void *(*GetDirectBufferAddress)(JNIEnv *env, jobject buf);
   jlong (*GetDirectBufferCapacity)(JNIEnv *env, jobject buf);
   jobject (*NewDirectByteBuffer)(JNIEnv *env, void *address, jlong capacity);
+  const char *(*GetStringUTFChars)(JNIEnv *env, jstring str, jboolean *isCopy);
+  void (*ReleaseStringUTFChars)(JNIEnv *env, jstring str, const char *chars);
 };
 #endif

@@ -39,11 +39,16 @@ JNIEXPORT jlong JNICALL Java_com_twitter_simclustersann_gpu_SannJni_indexBuild(J
                                                                                 jlongArray tweetIds, jdoubleArray scores) {
   (void)cls;
   sann_index_options_t o = {device, partitions, shardId, nShards};
+  if (!clusterIds || !listOffsets || !tweetIds || !scores) {
+    throw_runtime(env, "a list array is null");
+    return 0;
+  }
   const jsize n = (*env)->GetArrayLength(env, clusterIds);
   if ((*env)->GetArrayLength(env, listOffsets) != n + 1) {
     throw_runtime(env, "listOffsets must have clusterIds.length + 1 entries");
     return 0;
   }
+  const jsize n_t = (*env)->GetArrayLength(env, tweetIds), n_s = (*env)->GetArrayLength(env, scores);
   /* pinned, no copy; nothing between Get and Release may call back into the JVM */
   void *c = (*env)->GetPrimitiveArrayCritical(env, clusterIds, NULL);
   void *of = (*env)->GetPrimitiveArrayCritical(env, listOffsets, NULL);
@@ -51,11 +56,22 @@ JNIEXPORT jlong JNICALL Java_com_twitter_simclustersann_gpu_SannJni_indexBuild(J
   void *s = (*env)->GetPrimitiveArrayCritical(env, scores, NULL);
   sann_index_t *ix = NULL;
   int rc = SANN_ENOMEM;
-  if (c && of && t && s) rc = sann_index_build(&o, n, (const int32_t *)c, (const int64_t *)of, (const int64_t *)t, (const double *)s, &ix);
+  const char *bad = NULL;
+  if (c && of && t && s) {
+    /* sann_index_build reads tweetIds / scores up to listOffsets[n]: the Java arrays must reach that far (a short array
+     * would be a native read past the end of a Java heap object, not an exception) */
+    const int64_t *lo = (const int64_t *)of;
+    if (lo[0] < 0 || lo[n] < lo[0] || lo[n] > (int64_t)n_t || lo[n] > (int64_t)n_s) bad = "tweetIds / scores are shorter than listOffsets says";
+    else rc = sann_index_build(&o, n, (const int32_t *)c, lo, (const int64_t *)t, (const double *)s, &ix);
+  }
   if (s) (*env)->ReleasePrimitiveArrayCritical(env, scores, s, JNI_ABORT);
   if (t) (*env)->ReleasePrimitiveArrayCritical(env, tweetIds, t, JNI_ABORT);
   if (of) (*env)->ReleasePrimitiveArrayCritical(env, listOffsets, of, JNI_ABORT);
   if (c) (*env)->ReleasePrimitiveArrayCritical(env, clusterIds, c, JNI_ABORT);
+  if (bad) {
+    throw_runtime(env, bad);
+    return 0;
+  }
   if (rc != SANN_OK) {
     throw_runtime(env, rc == SANN_ENOMEM && !(c && of && t && s) ? "could not pin the list arrays" : sann_last_error());
     return 0;
@@ -102,14 +118,41 @@ JNIEXPORT jint JNICALL Java_com_twitter_simclustersann_gpu_SannJni_getTweetCandi
     throw_runtime(env, "a required direct buffer is null");
     return SANN_EINVAL;
   }
-  if ((*env)->GetDirectBufferCapacity(env, configs) < (jlong)nConfigs * (jlong)sizeof(sann_config_t) ||
-      (*env)->GetDirectBufferCapacity(env, outIds) < (jlong)nq * outStride * 8 ||
-      (*env)->GetDirectBufferCapacity(env, outScores) < (jlong)nq * outStride * 8 ||
-      (*env)->GetDirectBufferCapacity(env, outCounts) < (jlong)nq * 4 ||
-      (*env)->GetDirectBufferCapacity(env, outMapSizes) < (jlong)nq * 4) {
+  /* sizes first (a negative nq or stride would make every product below negative and every capacity "large enough") */
+  if (nq < 0 || outStride < 1 || (nConfigs != 1 && nConfigs != nq)) {
+    throw_runtime(env, "nq >= 0, outStride >= 1 and nConfigs in {1, nq}");
+    return SANN_EINVAL;
+  }
+#define CAP(x) ((*env)->GetDirectBufferCapacity(env, (x)))
+  if (CAP(configs) < (jlong)nConfigs * (jlong)sizeof(sann_config_t) || CAP(outIds) < (jlong)nq * outStride * 8 ||
+      CAP(outScores) < (jlong)nq * outStride * 8 || CAP(outCounts) < (jlong)nq * 4 || CAP(outMapSizes) < (jlong)nq * 4 ||
+      CAP(embOffsets) < ((jlong)nq + 1) * 8 || (sourceTweetIds && CAP(sourceTweetIds) < (jlong)nq * 8) ||
+      (hasSourceTweet && CAP(hasSourceTweet) < (jlong)nq) || (scanOffsets && CAP(scanOffsets) < ((jlong)nq + 1) * 8)) {
     throw_runtime(env, "a direct buffer is smaller than the batch needs");
     return SANN_EINVAL;
   }
+  if ((sourceTweetIds == NULL) != (hasSourceTweet == NULL) || (scanOffsets == NULL) != (scanClusterIds == NULL)) {
+    throw_runtime(env, "sourceTweetIds / hasSourceTweet and scanOffsets / scanClusterIds come in pairs");
+    return SANN_EINVAL;
+  }
+  {
+    /* the CSR regions the offsets name must lie inside their buffers */
+    const int64_t *eo = (const int64_t *)BUF(embOffsets);
+    const int64_t e0 = nq ? eo[0] : 0, e1 = nq ? eo[nq] : 0;
+    if (e0 < 0 || e1 < e0 ||
+        (e1 > e0 && (!embClusterIds || !embScores || CAP(embClusterIds) < e1 * 4 || CAP(embScores) < e1 * 8))) {
+      throw_runtime(env, "embClusterIds / embScores are smaller than embOffsets says");
+      return SANN_EINVAL;
+    }
+    if (scanOffsets && nq) {
+      const int64_t *so = (const int64_t *)BUF(scanOffsets);
+      if (so[0] < 0 || so[nq] < so[0] || CAP(scanClusterIds) < so[nq] * 4) {
+        throw_runtime(env, "scanClusterIds is smaller than scanOffsets says");
+        return SANN_EINVAL;
+      }
+    }
+  }
+#undef CAP
   const int rc = sann_get_tweet_candidates(
       (sann_index_t *)(intptr_t)index, variant, nowMs, nq, (const int64_t *)BUF(embOffsets), (const int32_t *)BUF(embClusterIds),
       (const double *)BUF(embScores), (const int64_t *)BUF(sourceTweetIds), (const uint8_t *)BUF(hasSourceTweet),
