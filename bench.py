@@ -84,9 +84,10 @@ def main():
                          "and out (N = 1 only; -1 = as many as --steps, 0 = skip)")
     ap.add_argument("--e2e-threads", type=int, default=4, help="concurrent callers of the end-to-end leg (the reference's callers are Finagle worker threads)")
     ap.add_argument("--e2e-query-sets", type=int, default=4, help="distinct query batches the end-to-end leg rotates through")
-    ap.add_argument("--mb-threads", type=int, default=512, help="caller threads of the micro-batched leg (0 = skip)")
-    ap.add_argument("--mb-requests", type=int, default=65536, help="single requests of the micro-batched leg, all threads together")
-    ap.add_argument("--mb-batch", type=int, default=512, help="max_batch of the micro-batching queue in that leg")
+    ap.add_argument("--mb-threads", type=int, default=8, help="caller threads of the micro-batched leg (0 = skip)")
+    ap.add_argument("--mb-window", type=int, default=128, help="single requests each caller thread keeps in flight (outstanding Futures)")
+    ap.add_argument("--mb-requests", type=int, default=262144, help="single requests of the micro-batched leg, all threads together")
+    ap.add_argument("--mb-batch", type=int, default=1024, help="max_batch of the micro-batching queue in that leg")
     ap.add_argument("--mb-wait-us", type=int, default=200, help="max_wait_us of the micro-batching queue in that leg")
     ap.add_argument("--mb-dispatchers", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cpu_count, 16))")
@@ -464,6 +465,36 @@ def main():
         run_callers(n_e2e, True)
         assert lib.sann_device_synchronize(local_rank) == 0
         e2e_elapsed = time.perf_counter() - t0
+        py_ms_per_step = e2e_elapsed / n_e2e * 1e3
+        # The same calls from NATIVE caller threads (tools/micro/batcher_load.c: e2e_load_run).  The Python callers above hold the
+        # interpreter lock while they marshal a call's arguments (~0.1 ms, half a GPU step), so what they time is the harness;
+        # the native callers time the library.  Same entry point, same query sets, same pinned response buffers.
+        native = None
+        load_so_e = os.path.join(ROOT, "tools", "micro", "libbatcher_load.so")
+        if os.path.exists(load_so_e):
+            ld = ctypes.CDLL(load_so_e)
+            PP = ctypes.c_void_p * n_sets
+            keep = [(np.ascontiguousarray(q[0], np.int64), np.ascontiguousarray(q[1], np.int32), np.ascontiguousarray(q[2], np.float64)) for q in qsets[:n_sets]]
+            a_o, a_c, a_s = PP(*[k_[0].ctypes.data for k_ in keep]), PP(*[k_[1].ctypes.data for k_ in keep]), PP(*[k_[2].ctypes.data for k_ in keep])
+            ld.e2e_load_run.restype = ctypes.c_int
+            ld.e2e_load_run.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)]
+            cfg_e = cfg.to_c()
+            r3 = (ctypes.c_double * 3)()
+            n_nat = max(n_e2e, 40)
+            for n_calls in (2 * n_thr, n_nat):
+                rc = ld.e2e_load_run(index.handle, n_thr, n_calls, nq, n_sets, a_o, a_c, a_s, ctypes.byref(cfg_e), now_ms, r3)
+                assert rc == 0, lib.sann_last_error()
+            native = (r3[0] / r3[1] * 1e3, r3[2] / r3[0], int(r3[1]))
+            if os.environ.get("SANN_TRACE_CALLS") == "1":
+                us4, n_tr = (ctypes.c_double * 4)(), ctypes.c_int64()
+                lib.sann_debug_call_trace(us4, ctypes.byref(n_tr))
+                print(f"e2e trace: {n_tr.value} calls; per call submit {us4[0] / max(n_tr.value, 1):.0f} us, enqueue copies {us4[1] / max(n_tr.value, 1):.0f} us, "
+                      f"wait kernels {us4[2] / max(n_tr.value, 1):.0f} us, wait copies {us4[3] / max(n_tr.value, 1):.0f} us", file=sys.stderr)
+            e2e_elapsed, n_e2e_timed = r3[0], int(r3[1])
+            cand_total = [int(r3[2])]
+        else:
+            n_e2e_timed = n_e2e
         # thread 0's first call answered query set 0 = the replayed batch: must be the same answer, bit for bit
         fa = first_answer[0]
         same = bool(np.array_equal(fa[2], counts) and np.array_equal(fa[3], msz) and
@@ -475,9 +506,10 @@ def main():
         for i in range(n_lat):
             sa.get_tweet_candidates(index, *qsets[i % n_sets], cfg, now_ms=now_ms, out=outs[0])
         lat_ms = (time.perf_counter() - t1) / n_lat * 1e3
-        e2e = {"value": sum(cand_total) / e2e_elapsed, "unit": "candidates/sec", "ms_per_step": e2e_elapsed / n_e2e * 1e3,
-               "steps": n_e2e, "callers": n_thr, "fresh_query_sets": n_sets, "single_call_latency_ms": lat_ms,
-               "equals_replayed_batch": same, "ratio_to_replay_step": (e2e_elapsed / n_e2e) / (elapsed / args.steps),
+        e2e = {"value": sum(cand_total) / e2e_elapsed, "unit": "candidates/sec", "ms_per_step": e2e_elapsed / n_e2e_timed * 1e3,
+               "steps": n_e2e_timed, "callers": n_thr, "caller_threads": "native (pthreads)" if native else "python",
+               "python_callers_ms_per_step": py_ms_per_step, "fresh_query_sets": n_sets, "single_call_latency_ms": lat_ms,
+               "equals_replayed_batch": same, "ratio_to_replay_step": (e2e_elapsed / n_e2e_timed) / (elapsed / args.steps),
                "what": "sann_get_tweet_candidates per step: pageable host query arrays in, packed H2D, device-side query "
                        "preparation, descriptor + unit + merge kernels, D2H of ids/scores/counts into pinned host arrays; "
                        "pooled batch objects, no allocation in steady state"}
@@ -491,28 +523,29 @@ def main():
     if not sharded and n_e2e > 0 and args.mb_threads > 0 and os.path.exists(load_so):
         load = ctypes.CDLL(load_so)
         load.batcher_load_run.restype = ctypes.c_int
-        load.batcher_load_run.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
-                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)]
+        load.batcher_load_run.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)]
         mb = pkg.MicroBatcher(index, max_batch=args.mb_batch, max_wait_us=args.mb_wait_us, n_dispatchers=args.mb_dispatchers)
         cfg_c = cfg.to_c()
         o_q, c_q, s_q = (np.ascontiguousarray(qsets[0][0], np.int64), np.ascontiguousarray(qsets[0][1], np.int32),
                          np.ascontiguousarray(qsets[0][2], np.float64))
         res = (ctypes.c_double * 6)()
-        per = max(8, args.mb_requests // args.mb_threads)
-        for n_req in (max(2, per // 8), per):  # a short warm-up run, then the measured one
-            rc = load.batcher_load_run(mb._h, args.mb_threads, n_req, nq, o_q.ctypes.data, c_q.ctypes.data, s_q.ctypes.data,
+        per = max(2 * args.mb_window, args.mb_requests // args.mb_threads)
+        for n_req in (2 * args.mb_window, per):  # a short warm-up run, then the measured one
+            rc = load.batcher_load_run(mb._h, args.mb_threads, args.mb_window, n_req, nq, o_q.ctypes.data, c_q.ctypes.data, s_q.ctypes.data,
                                        ctypes.byref(cfg_c), now_ms, res)
             assert rc == 0, lib.sann_last_error()
         st_mb = mb.stats()
         mb.close()
         mb_leg = {"value": res[2] / res[0], "unit": "candidates/sec", "requests_per_sec": res[1] / res[0], "requests": int(res[1]),
-                  "caller_threads": args.mb_threads, "latency_us_p50": res[3], "latency_us_p99": res[4], "latency_us_max": res[5],
+                  "caller_threads": args.mb_threads, "requests_in_flight_per_caller": args.mb_window, "latency_us_p50": res[3], "latency_us_p99": res[4], "latency_us_max": res[5],
                   "max_batch": args.mb_batch, "max_wait_us": args.mb_wait_us, "dispatchers": args.mb_dispatchers,
                   "mean_batch": st_mb.n_requests / max(st_mb.n_batches, 1), "batches_closed_full": int(st_mb.n_closed_full),
                   "batches_closed_by_deadline": int(st_mb.n_closed_by_deadline),
-                  "what": "one blocking sann_batcher_get_tweet_candidates per caller thread at a time (native pthreads, "
-                          "tools/micro/batcher_load.c), folded into batches by the library's micro-batching queue; every request "
-                          "pays its copy into the open batch, the batch's whole boundary call and the copy of its rows"}
+                  "what": "single getTweetCandidates requests through sann_submit / sann_wait from native caller threads that each keep a "
+                          "window of requests in flight (tools/micro/batcher_load.c), folded into batches by the library's micro-batching "
+                          "queue; every request pays its copy into the open batch, the batch's whole boundary call and the copy of its rows; "
+                          "latency = submit -> collected"}
 
     if rank != 0:
         if sharded:

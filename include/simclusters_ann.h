@@ -389,6 +389,11 @@ int sann_batcher_get_tweet_candidates(sann_batcher_t *batcher, int64_t now_ms, i
                                       int32_t *out_count, int32_t *out_map_size);
 int sann_batcher_stats(sann_batcher_t *batcher, sann_batcher_stats_t *stats);
 
+/* Measurement: with SANN_TRACE_CALLS=1 in the environment every sann_get_tweet_candidates[_at] call adds the wall time of its
+ * four stages -- argument pass + packing + H2D + preparation launch | kernel launches | wait for the kernels + status | copy
+ * of the answer + wait -- to process-wide totals; this returns (us4[4], microseconds) and resets them. */
+int sann_debug_call_trace(double *us4, int64_t *calls);
+
 /* Pinned (page-locked) host memory for request / response buffers a shim keeps across calls (e.g. behind a direct
  * ByteBuffer): device copies to and from it run at PCIe speed instead of being staged through the runtime. */
 int sann_host_alloc(int64_t bytes, void **out);

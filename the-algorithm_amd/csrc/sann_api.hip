@@ -11,6 +11,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <limits>
 #include <cmath>
 #include <cstdio>
@@ -1161,14 +1166,36 @@ int sann_batch_finish(sann_batch_t *b, void *hip_stream) try {
 
 // enqueue the copies of a batch's results to the host on `st` (sync = false: the caller synchronises the stream)
 static int results_impl(sann_batch_t *b, hipStream_t st, int64_t *out_ids, double *out_scores, int32_t out_stride,
-                        int32_t *out_counts, int32_t *out_map_sizes, bool sync = true) {
+                        int32_t *out_counts, int32_t *out_map_sizes, bool sync = true, bool by_kernel = true) {
   if (b->nq == 0) return SANN_OK;
   if (out_stride < b->stride) return fail(SANN_EINVAL, "out_stride smaller than the batch's max k");
   if (b->bound_chunk_q > 0) return fail(SANN_EINVAL, "outputs are bound to caller-owned chunked buffers");
   HIP_TRY(hipSetDevice(b->ix->device));
   BatchView bv = b->view();
-  // rows are contiguous when the caller's stride is the batch's: one copy per array (at PCIe speed into pinned
-  // memory, see sann_host_alloc; staged by the runtime into pageable memory)
+  // All four arrays in pinned memory (sann_host_alloc: what a shim keeps across calls): a small kernel writes the answer
+  // straight into them over PCIe -- one launch, and indifferent to what the runtime's copy path decides.  hipMemcpyAsync into
+  // the same buffers is the faster way home while at least two other batches keep the GPU busy (0.235 against 0.287 ms per
+  // 1024-query call with three callers and more), and much the slower one otherwise (0.93 / 0.77 ms against 0.46 / 0.41 with
+  // one / two callers: tools/e2e_probe.py) -- the engine says which regime it is in (by_kernel).  Anything else (pageable
+  // arrays, a missing array) takes the runtime's copies.
+  if (by_kernel && out_ids && out_scores && out_counts && out_map_sizes) {
+    void *d[4] = {nullptr, nullptr, nullptr, nullptr};
+    const void *h[4] = {out_ids, out_scores, out_counts, out_map_sizes};
+    bool pinned = true;
+    for (int i = 0; i < 4 && pinned; i++) {
+      hipPointerAttribute_t at;
+      pinned = hipPointerGetAttributes(&at, h[i]) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr;
+      if (pinned) d[i] = at.devicePointer;
+    }
+    (void)hipGetLastError();  // (an unregistered pointer is reported as an error by some runtime versions: not ours)
+    if (pinned) {
+      HIP_TRY(launch_copy_out(b->nq, b->stride, out_stride, bv.out_ids, bv.out_scores, bv.out_counts, bv.out_map_sizes, (int64_t *)d[0],
+                              (double *)d[1], (int32_t *)d[2], (int32_t *)d[3], st));
+      if (sync) HIP_TRY(hipStreamSynchronize(st));
+      return SANN_OK;
+    }
+  }
+  // rows are contiguous when the caller's stride is the batch's: one copy per array (staged by the runtime into pageable memory)
   const size_t row = (size_t)b->stride * 8;
   if (out_ids) {
     if (out_stride == b->stride) HIP_TRY(hipMemcpyAsync(out_ids, bv.out_ids, row * (size_t)b->nq, hipMemcpyDeviceToHost, st));
@@ -1428,7 +1455,9 @@ int sann_device_synchronize(int32_t device) try {
 } ABI_CATCH
 
 }  // extern "C"
+void sann_engine_stop(sann_index *ix);
 sann_index::~sann_index() {
+  sann_engine_stop(this);
   for (sann_batch *b : pool) delete b;
 }
 extern "C" {
@@ -1444,6 +1473,224 @@ int sann_batch_destroy(sann_batch_t *b) try {
 // a batch object of its own, taken from the index's pool and given back afterwards, on that object's own non-blocking
 // stream: after the first few calls nothing is allocated, and callers on different threads overlap on the GPU.
 }  // extern "C"
+static std::atomic<double> g_trace_us[4];
+static std::atomic<int64_t> g_trace_calls{0};
+static inline void operator+=(std::atomic<double> &a, double v) { double o = a.load(); while (!a.compare_exchange_weak(o, o + v)) {} }
+extern "C" int sann_debug_call_trace(double *us4, int64_t *calls) {
+  for (int i = 0; i < 4; i++) { if (us4) us4[i] = g_trace_us[i].load(); g_trace_us[i].store(0.0); }
+  if (calls) *calls = g_trace_calls.exchange(0);
+  return SANN_OK;
+}
+// ---------------------------------------------------------------------------------------------------------------------------
+// The submission engine of the boundary call.
+//
+// sann_get_tweet_candidates is called from many threads at once (Finagle workers; the micro-batcher's dispatchers).  Until
+// round 3 every caller drove its own pooled batch on its own stream -- reset, launches, a blocking wait, the copies home,
+// another blocking wait -- and the HIP runtime serialised them: with four native callers the argument pass + H2D + one kernel
+// launch of a call took 377 us of wall time instead of 18 (tools/e2e_probe.py), and a 1024-query call cost 1.6 x the GPU's
+// step.  Now ONE thread per index makes every HIP call of this path, and it never waits while it could be submitting:
+//
+//   callers       hand over a job (their argument pointers stay valid: they block until the job is done) and sleep
+//   the engine    for each job: batch_reset + kernels on one of its three streams, the unit kernel chained behind the
+//                 previous job's (as bench.py's replay loop does); up to two jobs run ahead; then, oldest job first:
+//                 finish (wait for ITS kernels, slow tail if flagged) -> copies of the answer enqueued -> the next job is
+//                 submitted while they fly -> wait for the copies -> wake the caller
+//
+// so job i's copies home overlap job i+1's kernels, job i+2's argument pass overlaps both, and nobody contends for the
+// runtime's locks.  SANN_ENGINE=0 restores the per-caller path (kept: it is the simplest statement of the call).
+static bool trace_on() {
+  static const bool t = [] { const char *e = getenv("SANN_TRACE_CALLS"); return e && e[0] == '1'; }();
+  return t;
+}
+static double trace_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool memcpy_when_busy() {  // SANN_COPY_MEMCPY=1: the runtime's copies instead of the copy kernel while the pipeline is full
+  static const bool t = [] { const char *e = getenv("SANN_COPY_MEMCPY"); return e && e[0] == '1'; }();
+  return t;
+}
+struct EngineJob {
+  // arguments of sann_candidates_pooled
+  int32_t variant, nq, n_configs, out_stride;
+  int64_t now_ms;
+  const int64_t *now_ms_q, *emb_offsets, *source_tweet_ids, *scan_offsets;
+  const int32_t *emb_cluster_ids, *scan_cluster_ids;
+  const double *emb_scores;
+  const uint8_t *has_source_tweet;
+  const sann_config_t *configs;
+  int64_t *out_ids;
+  double *out_scores;
+  int32_t *out_counts, *out_map_sizes;
+  // state
+  sann_batch *b = nullptr;
+  int slot = 0;
+  int stage = 0;  // 1 kernels enqueued, 2 copies enqueued
+  int rc = SANN_OK;
+  std::string msg;
+  std::mutex m;
+  std::condition_variable cv;
+  bool done = false;
+};
+
+struct sann_engine {
+  sann_index *ix;
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<EngineJob *> queue;
+  bool stop = false;
+  static constexpr int kStreams = 3;
+  hipStream_t streams[kStreams] = {nullptr, nullptr, nullptr};
+  hipEvent_t copied[kStreams] = {nullptr, nullptr, nullptr};
+
+  void finish_job(EngineJob *j) {
+    std::string keep = g_err;
+    {  // the batch object goes back to the pool (a device error may have left it in an unknown state: dropped then)
+      bool pooled = false;
+      if (j->b && (j->rc == SANN_OK || j->rc == SANN_EINVAL || j->rc == SANN_ELIMIT)) {
+        std::lock_guard<std::mutex> lk(ix->pool_mu);
+        if (ix->pool.size() < 16) {
+          ix->pool.push_back(j->b);
+          pooled = true;
+        }
+      }
+      if (!pooled && j->b) {
+        (void)hipStreamSynchronize(streams[j->slot]);
+        delete j->b;
+      }
+      j->b = nullptr;
+    }
+    if (j->rc != SANN_OK) j->msg = keep;
+    {
+      std::lock_guard<std::mutex> lk(j->m);
+      j->done = true;
+    }
+    j->cv.notify_one();
+  }
+
+  // reset + kernels of a job on stream `slot`, its unit kernel behind `prev`'s
+  void submit(EngineJob *j, int slot, sann_batch *prev) {
+    j->slot = slot;
+    sann_batch *b = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(ix->pool_mu);
+      if (!ix->pool.empty()) {
+        b = ix->pool.back();
+        ix->pool.pop_back();
+      }
+    }
+    if (!b) {
+      b = new (std::nothrow) sann_batch();
+      if (!b) {
+        j->rc = fail(SANN_ENOMEM, "out of host memory");
+        return;
+      }
+      b->ix = ix;
+    }
+    j->b = b;
+    b->variant = j->variant;
+    hipStream_t st = streams[slot];
+    j->rc = batch_reset(b, st, j->now_ms, j->nq, j->emb_offsets, j->emb_cluster_ids, j->emb_scores, j->source_tweet_ids,
+                        j->has_source_tweet, j->configs, j->n_configs, j->scan_offsets, j->scan_cluster_ids, j->now_ms_q);
+    if (j->rc == SANN_OK) j->rc = sann_batch_run_after(b, st, prev, 0);
+    if (j->rc == SANN_OK) j->stage = 1;
+  }
+
+  void run() {
+    (void)hipSetDevice(ix->device);
+    for (int i = 0; i < kStreams; i++) {
+      (void)hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking);
+      (void)hipEventCreateWithFlags(&copied[i], hipEventDisableTiming);
+    }
+    std::deque<EngineJob *> inflight;  // oldest first; at most kStreams
+    int next_slot = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      // submit what is waiting, up to two jobs ahead of the one whose answer is being collected
+      while (!queue.empty() && (int)inflight.size() < kStreams) {
+        EngineJob *j = queue.front();
+        queue.pop_front();
+        lk.unlock();
+        sann_batch *prev = nullptr;
+        for (auto it = inflight.rbegin(); it != inflight.rend(); ++it)
+          if ((*it)->stage == 1 && (*it)->b) { prev = (*it)->b; break; }
+        const double t_s = trace_on() ? trace_now() : 0.0;
+        submit(j, next_slot, prev);
+        if (trace_on()) { g_trace_us[0] += trace_now() - t_s; g_trace_calls++; }
+        if (j->rc != SANN_OK) finish_job(j);
+        else {
+          inflight.push_back(j);
+          next_slot = (next_slot + 1) % kStreams;
+        }
+        lk.lock();
+      }
+      if (inflight.empty()) {
+        if (stop) break;
+        cv.wait(lk);
+        continue;
+      }
+      lk.unlock();
+      EngineJob *j = inflight.front();
+      if (j->stage == 1) {
+        // its kernels (the next job's are already queued behind them on another stream): wait, settle, send the answer home
+        hipStream_t st = streams[j->slot];
+        const double t_f = trace_on() ? trace_now() : 0.0;
+        j->rc = sann_batch_finish(j->b, st);
+        const double t_r = trace_on() ? trace_now() : 0.0;
+        if (j->rc == SANN_OK)
+          j->rc = results_impl(j->b, st, j->out_ids, j->out_scores, j->out_stride, j->out_counts, j->out_map_sizes, false,
+                               /* by_kernel = */ !memcpy_when_busy() || inflight.size() < (size_t)kStreams);
+        if (trace_on()) { g_trace_us[2] += t_r - t_f; g_trace_us[1] += trace_now() - t_r; }
+        if (j->rc != SANN_OK) {
+          inflight.pop_front();
+          finish_job(j);
+        } else {
+          j->stage = 2;
+          // (back to the top: whatever is queued is submitted while the copies fly)
+        }
+      } else {
+        const double t_w = trace_on() ? trace_now() : 0.0;
+        // (the stream holds nothing but this job: a slot is reused only after its job has left `inflight`)
+        if (hipStreamSynchronize(streams[j->slot]) != hipSuccess) j->rc = fail(SANN_EDEVICE, "hipStreamSynchronize");
+        if (trace_on()) g_trace_us[3] += trace_now() - t_w;
+        inflight.pop_front();
+        finish_job(j);
+      }
+      lk.lock();
+    }
+    lk.unlock();
+    for (int i = 0; i < kStreams; i++) {
+      if (streams[i]) (void)hipStreamDestroy(streams[i]);
+      if (copied[i]) (void)hipEventDestroy(copied[i]);
+    }
+  }
+};
+
+static sann_engine *engine_of(sann_index *ix) {
+  std::lock_guard<std::mutex> lk(ix->engine_mu);
+  if (!ix->engine) {
+    sann_engine *e = new sann_engine();
+    e->ix = ix;
+    e->th = std::thread([e] { e->run(); });
+    ix->engine = e;
+  }
+  return ix->engine;
+}
+void sann_engine_stop(sann_index *ix) {
+  sann_engine *e = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(ix->engine_mu);
+    e = ix->engine;
+    ix->engine = nullptr;
+  }
+  if (!e) return;
+  {
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->stop = true;
+  }
+  e->cv.notify_all();
+  e->th.join();
+  delete e;
+}
+
 int sann_candidates_pooled(sann_index_t *index, int32_t variant, int64_t now_ms, const int64_t *now_ms_q, int32_t nq,
                            const int64_t *emb_offsets, const int32_t *emb_cluster_ids, const double *emb_scores,
                            const int64_t *source_tweet_ids, const uint8_t *has_source_tweet,
@@ -1452,6 +1699,27 @@ int sann_candidates_pooled(sann_index_t *index, int32_t variant, int64_t now_ms,
                            int32_t out_stride, int32_t *out_counts, int32_t *out_map_sizes) {
   if (!index) return fail(SANN_EINVAL, "index is NULL");
   if (variant < 0 || variant > 3) return fail(SANN_EINVAL, "unknown variant");
+  static const bool use_engine = [] { const char *e = getenv("SANN_ENGINE"); return !(e && e[0] == '0'); }();
+  if (use_engine) {
+    EngineJob j;
+    j.variant = variant; j.nq = nq; j.n_configs = n_configs; j.out_stride = out_stride; j.now_ms = now_ms; j.now_ms_q = now_ms_q;
+    j.emb_offsets = emb_offsets; j.source_tweet_ids = source_tweet_ids; j.scan_offsets = scan_offsets;
+    j.emb_cluster_ids = emb_cluster_ids; j.scan_cluster_ids = scan_cluster_ids; j.emb_scores = emb_scores;
+    j.has_source_tweet = has_source_tweet; j.configs = configs; j.out_ids = out_ids; j.out_scores = out_scores;
+    j.out_counts = out_counts; j.out_map_sizes = out_map_sizes;
+    sann_engine *e = engine_of(index);
+    {
+      std::lock_guard<std::mutex> lk(e->mu);
+      e->queue.push_back(&j);
+    }
+    e->cv.notify_one();
+    {
+      std::unique_lock<std::mutex> lk(j.m);
+      j.cv.wait(lk, [&] { return j.done; });
+    }
+    if (j.rc != SANN_OK) return fail(j.rc, j.msg);
+    return SANN_OK;
+  }
   sann_batch *b = nullptr;
   {
     std::lock_guard<std::mutex> lk(index->pool_mu);
@@ -1465,6 +1733,8 @@ int sann_candidates_pooled(sann_index_t *index, int32_t variant, int64_t now_ms,
     b = new (std::nothrow) sann_batch();
     if (!b) return fail(SANN_ENOMEM, "out of host memory");
     b->ix = index;
+  }
+  if (!b->own_stream) {
     hipError_t e = hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
       delete b;
@@ -1473,15 +1743,25 @@ int sann_candidates_pooled(sann_index_t *index, int32_t variant, int64_t now_ms,
   }
   b->variant = variant;
   hipStream_t st = b->own_stream;
+  // SANN_TRACE_CALLS=1: wall time per stage of this call, summed over the process (printed by sann_debug_call_trace)
+  static const bool trace = [] { const char *e = getenv("SANN_TRACE_CALLS"); return e && e[0] == '1'; }();
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_a = trace ? now_us() : 0.0;
   int rc = batch_reset(b, st, now_ms, nq, emb_offsets, emb_cluster_ids, emb_scores, source_tweet_ids, has_source_tweet,
                        configs, n_configs, scan_offsets, scan_cluster_ids, now_ms_q);
+  const double t_b = trace ? now_us() : 0.0;
   if (rc == SANN_OK) rc = sann_batch_run(b, st);
-  // (Round 3 tried to enqueue the copies of the answer right behind the merge kernel, before the host has looked at the batch's
-  // status -- one host round trip per call instead of two.  With several callers it ran 3.5 x SLOWER, 1.16 ms instead of 0.33 ms
-  // per 1024-query call with four callers: a copy that waits for its own stream's kernels sits in the copy engine's queue in
-  // front of the other callers' copies.  The copies are enqueued when the kernels have finished.)
+  const double t_c = trace ? now_us() : 0.0;
+  // (the copies of the answer are enqueued when the kernels have finished: a copy that waits for its own stream's kernels sits
+  // in the copy engine's queue in front of the other callers' copies -- measured 1.16 ms instead of 0.33 ms per call, four callers)
   if (rc == SANN_OK) rc = sann_batch_finish(b, st);
+  const double t_d = trace ? now_us() : 0.0;
   if (rc == SANN_OK) rc = results_impl(b, st, out_ids, out_scores, out_stride, out_counts, out_map_sizes);
+  if (trace) {
+    const double t_e = now_us();
+    g_trace_us[0] += t_b - t_a; g_trace_us[1] += t_c - t_b; g_trace_us[2] += t_d - t_c; g_trace_us[3] += t_e - t_d;
+    g_trace_calls++;
+  }
   std::string keep = g_err;
   bool pooled = false;
   if (rc == SANN_OK || rc == SANN_EINVAL || rc == SANN_ELIMIT) {  // a device error may have left the object in an unknown state

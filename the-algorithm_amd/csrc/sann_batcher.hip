@@ -105,9 +105,10 @@ struct sann_batcher {
   std::unique_ptr<Batch> open;                 // accepting requests (never null)
   std::deque<std::unique_ptr<Batch>> ready;    // closed, waiting for a dispatcher
   std::vector<std::unique_ptr<Batch>> spare;   // recycled
+  std::mutex tk_mu;  // the ticket table has a lock of its own: collecting answers does not hold up submissions
   std::unordered_map<int64_t, std::shared_ptr<Request>> tickets;
   std::vector<std::thread> workers;
-  int64_t next_ticket = 1;
+  std::atomic<int64_t> next_ticket{1};
   bool stop = false;
   // statistics
   int64_t n_requests = 0, n_batches = 0, n_full = 0, n_timeout = 0, max_batch_seen = 0;
@@ -116,7 +117,12 @@ struct sann_batcher {
     if (open->reqs.empty()) return;
     ready.push_back(std::move(open));
     if (!spare.empty()) { open = std::move(spare.back()); spare.pop_back(); }
-    else open.reset(new Batch());
+    else {
+      open.reset(new Batch());
+      open->reqs.reserve((size_t)opt.max_batch);
+      open->cids.reserve((size_t)opt.max_batch * 64);
+      open->scores.reserve((size_t)opt.max_batch * 64);
+    }
     cv_work.notify_one();
   }
 
@@ -244,14 +250,23 @@ int sann_submit(sann_batcher_t *b, int64_t now_ms, int32_t n_embedding, const in
   const int k = config->max_num_results < 1000 ? (config->max_num_results < 0 ? 0 : config->max_num_results) : 1000;
   if (out_capacity < k || (k > 0 && (!out_ids || !out_scores))) return fail(SANN_EINVAL, "out_capacity must hold min(maxNumResults, 1000) results");
   std::shared_ptr<Request> r(new Request());
+  r->ticket = b->next_ticket.fetch_add(1, std::memory_order_relaxed);
   r->out_cap = out_capacity;
   r->out_ids = out_ids;
   r->out_scores = out_scores;
   r->out_count = out_count;
   r->out_map_size = out_map_size;
   {
+    std::lock_guard<std::mutex> lk(b->tk_mu);
+    b->tickets.emplace(r->ticket, r);
+  }
+  {
     std::lock_guard<std::mutex> lk(b->mu);
-    if (b->stop) return fail(SANN_EINVAL, "the batcher is shutting down");
+    if (b->stop) {
+      std::lock_guard<std::mutex> lk2(b->tk_mu);
+      b->tickets.erase(r->ticket);
+      return fail(SANN_EINVAL, "the batcher is shutting down");
+    }
     Batch &bt = *b->open;
     if (bt.reqs.empty()) bt.deadline = Clock::now() + std::chrono::microseconds(b->opt.max_wait_us);
     bt.cids.insert(bt.cids.end(), cluster_ids, cluster_ids + n_embedding);
@@ -262,10 +277,8 @@ int sann_submit(sann_batcher_t *b, int64_t now_ms, int32_t n_embedding, const in
     bt.now.push_back(now_ms);
     bt.cfgs.push_back(*config);
     bt.kmax = std::max(bt.kmax, k);
-    r->ticket = b->next_ticket++;
     r->sync = bt.sync;
     bt.reqs.push_back(r);
-    b->tickets.emplace(r->ticket, r);
     b->n_requests++;
     const bool first = bt.reqs.size() == 1;
     if ((int)bt.reqs.size() >= b->opt.max_batch) {
@@ -282,7 +295,7 @@ int sann_submit(sann_batcher_t *b, int64_t now_ms, int32_t n_embedding, const in
 static int collect(sann_batcher *b, int64_t ticket, bool block, int32_t *done) {
   std::shared_ptr<Request> r;
   {
-    std::lock_guard<std::mutex> lk(b->mu);
+    std::lock_guard<std::mutex> lk(b->tk_mu);
     auto it = b->tickets.find(ticket);
     if (it == b->tickets.end()) return fail(SANN_EINVAL, "unknown ticket (already collected?)");
     r = it->second;
@@ -296,7 +309,7 @@ static int collect(sann_batcher *b, int64_t ticket, bool block, int32_t *done) {
   if (done) *done = is_done ? 1 : 0;
   if (!is_done) return SANN_OK;
   {
-    std::lock_guard<std::mutex> lk(b->mu);
+    std::lock_guard<std::mutex> lk(b->tk_mu);
     if (b->tickets.erase(ticket) == 0) return fail(SANN_EINVAL, "unknown ticket (already collected?)");
   }
   if (r->status != SANN_OK) return fail(r->status, r->message);

@@ -96,6 +96,9 @@ struct sann_index {
   // batch objects kept for sann_get_tweet_candidates (one per concurrent caller), reset per call
   std::mutex pool_mu;
   std::vector<struct sann_batch *> pool;
+  // the submission engine of sann_get_tweet_candidates (one thread that owns every HIP call of the pooled path; made on first use)
+  std::mutex engine_mu;
+  struct sann_engine *engine = nullptr;
   ~sann_index();
 
   sann::IndexView view() const {

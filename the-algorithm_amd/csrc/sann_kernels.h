@@ -17,6 +17,12 @@ hipError_t launch_merge_shards(int n_shards, int nq, int stride, int64_t pitch, 
                                int out_stride, int64_t *out_ids, double *out_scores, int32_t *out_counts,
                                int32_t *out_map_sizes, int32_t *inexact, hipStream_t stream);
 
+// The answer of a batch written straight into the caller's PINNED host arrays by a (small) kernel: rows of `stride` entries ->
+// rows of `out_stride`, plus the two per-query int arrays.  A dozen workgroups keep the PCIe link busy and leave the CUs to the
+// next batch's kernels; unlike hipMemcpyAsync its cost does not depend on what else the runtime finds the stream doing.
+hipError_t launch_copy_out(int nq, int stride, int out_stride, const int64_t *ids, const double *scores, const int32_t *counts,
+                           const int32_t *map_sizes, int64_t *h_ids, double *h_scores, int32_t *h_counts, int32_t *h_map_sizes,
+                           hipStream_t stream);
 hipError_t launch_debug_normalise(int alg, int n, const double *dot, const double *nsq, double l2norm, double lognorm,
                                   double *out, hipStream_t stream);
 

@@ -28,6 +28,8 @@
 // Compiled with -ffp-contract=off (see sann_math.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "sann_device.h"
 #include "sann_kernels.h"
 #include "sann_math.h"
@@ -1195,6 +1197,43 @@ __global__ __launch_bounds__(WG) void merge_shards_kernel(int n_shards, int nq, 
     out_map_sizes[q] = m;
     if (bad && inexact) atomicAdd(inexact, 1);
   }
+}
+
+// Results -> the caller's pinned host arrays (see sann_kernels.h).  16-byte stores, consecutive lanes = consecutive addresses of
+// one row pair; rows of the two big arrays are re-pitched from `stride` to `out_stride` entries.
+__global__ __launch_bounds__(256) void copy_out_kernel(int nq, int stride, int out_stride, const int64_t *ids, const double *scores,
+                                                       const int32_t *counts, const int32_t *map_sizes, int64_t *h_ids,
+                                                       double *h_scores, int32_t *h_counts, int32_t *h_map_sizes) {
+  const int64_t n = (int64_t)nq * stride;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (out_stride == stride && (stride & 1) == 0) {
+    const ulonglong2 *a = reinterpret_cast<const ulonglong2 *>(ids), *c = reinterpret_cast<const ulonglong2 *>(scores);
+    ulonglong2 *ha = reinterpret_cast<ulonglong2 *>(h_ids), *hc = reinterpret_cast<ulonglong2 *>(h_scores);
+    for (int64_t i = i0; i < n / 2; i += step) {
+      ha[i] = a[i];
+      hc[i] = c[i];
+    }
+  } else {
+    for (int64_t i = i0; i < n; i += step) {
+      const int64_t q = i / stride, j = i - q * stride;
+      h_ids[q * out_stride + j] = ids[i];
+      h_scores[q * out_stride + j] = scores[i];
+    }
+  }
+  for (int64_t i = i0; i < nq; i += step) {
+    h_counts[i] = counts[i];
+    h_map_sizes[i] = map_sizes[i];
+  }
+}
+hipError_t launch_copy_out(int nq, int stride, int out_stride, const int64_t *ids, const double *scores, const int32_t *counts,
+                           const int32_t *map_sizes, int64_t *h_ids, double *h_scores, int32_t *h_counts, int32_t *h_map_sizes,
+                           hipStream_t stream) {
+  if (nq <= 0) return hipSuccess;
+  static const int wgs = [] { const char *e = getenv("SANN_COPY_WGS"); const int v = e ? atoi(e) : 16; return v >= 1 && v <= 1024 ? v : 16; }();
+  hipLaunchKernelGGL(copy_out_kernel, dim3(wgs), dim3(256), 0, stream, nq, stride, out_stride, ids, scores, counts, map_sizes, h_ids,
+                     h_scores, h_counts, h_map_sizes);
+  return hipGetLastError();
 }
 
 // Audit hook: out[i] = normalise(alg, dot[i], nsq[i], l2norm, lognorm) -- lets a test check the

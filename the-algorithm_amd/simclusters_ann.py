@@ -195,6 +195,7 @@ _PROTOS = {
     "sann_poll": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
     "sann_batcher_get_tweet_candidates": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sann_batcher_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sann_debug_call_trace": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "sann_debug_normalise": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
     "sann_debug_wave_sort": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p]),
     "sann_debug_approx": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
