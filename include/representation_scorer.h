@@ -69,6 +69,22 @@ int rsx_store_pair_scores(const rsx_store_t *a, const rsx_store_t *b, int32_t al
 int rsx_store_list_scores(const rsx_store_t *targets, const rsx_store_t *candidates, int32_t algorithm, int64_t target_id,
                           int32_t n_candidates, const int64_t *candidate_ids, double *out_scores, uint8_t *out_present);
 
+/* The heavy-rank step of the legacy SimClusters-ANN candidate source ON THE DEVICE, for nq queries at once (one workgroup per
+ * query): HeavyRanker.UniformScoreStoreRanker.rank (src/scala/com/twitter/simclusters_v2/candidate_source/HeavyRanker.scala:28-69)
+ * followed by reranking's sort and cut (SimClustersANNCandidateSource.scala:182-200).  Query q's light candidates are the first
+ * d_light_counts[q] (<= 1024) tweet ids of row q of d_light_ids (rows of light_stride entries: the device results of a
+ * SimClusters-ANN batch, already cut at maxReRankingCandidates); each is scored as pair(source_store[d_source_ids[q]],
+ * tweet_store[candidate]) -- both sides hydrated by id inside the kernel; a missing side is the reference's None and drops the
+ * candidate -- kept if score >= min_score (:63), sorted by score descending (ties: tweet id ascending), cut at
+ * max_num_results (<= out_stride).  All pointers are device pointers; asynchronous on hip_stream.  sann_heavy_rank
+ * (include/simclusters_ann.h) is the fused call a shim binds. */
+int rsx_heavy_rank_device(const rsx_store_t *source_store, const rsx_store_t *tweet_store, void *hip_stream, int32_t algorithm,
+                          int32_t nq, const void *d_source_ids, const void *d_light_ids, const void *d_light_counts,
+                          int32_t light_stride, double min_score, int32_t max_num_results, int32_t out_stride, void *d_out_ids,
+                          void *d_out_scores, void *d_out_counts);
+/* The device a store lives on. */
+int rsx_store_device(const rsx_store_t *store, int32_t *device);
+
 /* Scorer.computeSimilarityScoresPerTweet (representation-scorer/.../twistlyfeatures/Scorer.scala:157-369) with
  * Scorer.avg / Scorer.max (:426-429), for n_candidates tweets at once.
  *   maps:   map m = the ids that were scored against every candidate through store map_stores[m]

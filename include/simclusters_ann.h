@@ -394,6 +394,37 @@ int sann_batcher_stats(sann_batcher_t *batcher, sann_batcher_stats_t *stats);
  * of the answer + wait -- to process-wide totals; this returns (us4[4], microseconds) and resets them. */
 int sann_debug_call_trace(double *us4, int64_t *calls);
 
+/*
+ * The legacy in-process candidate source END TO END for a batch of queries (src/scala/com/twitter/simclusters_v2/
+ * candidate_source/SimClustersANNCandidateSource.scala:107-200): the light rank (SANN_VARIANT_LEGACY) and, when
+ * enable_heavy_ranking, the heavy rank fused behind it on the device -- the light top maxReRankingCandidates never leave HBM:
+ *   fetchCandidates          accumulate / partial normalisation / sort (:107-181)             the batch kernels, legacy variant
+ *   reranking                candidates.take(maxReRankingCandidates) -> HeavyRanker.rank -> sortBy(-score) -> take(maxNumResults)
+ *                            (:182-200; HeavyRanker.scala:28-69: pair score of (source embedding id, candidate tweet) through the
+ *                            uniform scoring store, kept if >= minScore)                        rsx_heavy_rank_device
+ * source_store / tweet_store are representation-scorer stores (include/representation_scorer.h: rsx_store_t) on the index's
+ * device; source_internal_ids[q] = the id the heavy ranker looks query q's source embedding up under.  Without heavy ranking
+ * the stores may be NULL and the result is the light ranking cut at max_num_results (minScore does not apply there: :160-180).
+ * Host arrays in and out, as sann_get_tweet_candidates; thread-safe.
+ */
+struct rsx_store;
+typedef struct sann_legacy_config {      /* case class SimClustersANNConfig of the legacy source, :214-260 */
+  int32_t max_num_results;
+  int32_t max_tweet_candidate_age_hours, min_tweet_candidate_age_hours;
+  int32_t candidate_embedding_type;       /* carried; the tweet store given here IS that type's store */
+  double min_score;                       /* heavy rank only */
+  int32_t enable_partial_normalization;   /* 0: dot product */
+  int32_t enable_heavy_ranking;
+  int32_t ranking_algorithm;              /* score.thrift ScoringAlgorithm 1..7 (RSX_PAIR_*); 6 = the "log" partial normalisation */
+  int32_t max_reranking_candidates;       /* <= 1000 */
+  int32_t max_top_tweets_per_cluster, max_scan_clusters;
+} sann_legacy_config_t;
+int sann_heavy_rank(sann_index_t *index, const struct rsx_store *source_store, const struct rsx_store *tweet_store, int64_t now_ms,
+                    int32_t nq, const int64_t *emb_offsets, const int32_t *emb_cluster_ids, const double *emb_scores,
+                    const int64_t *source_tweet_ids, const uint8_t *has_source_tweet, const int64_t *source_internal_ids,
+                    const sann_legacy_config_t *config, int64_t *out_ids, double *out_scores, int32_t out_stride,
+                    int32_t *out_counts);
+
 /* Pinned (page-locked) host memory for request / response buffers a shim keeps across calls (e.g. behind a direct
  * ByteBuffer): device copies to and from it run at PCIe speed instead of being staged through the runtime. */
 int sann_host_alloc(int64_t bytes, void **out);

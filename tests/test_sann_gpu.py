@@ -728,3 +728,76 @@ def test_legacy_source_with_heavy_ranking(pkg, oracle, small):
     assert [t for t, _ in light] == l_ids[:60].tolist()
     assert np.array_equal(np.array([s for _, s in light]).view(np.int64), l_sc[:60].view(np.int64))
     src_store.close(); tw_store.close(); index.close()
+
+
+def test_heavy_rank_batch_behind_the_c_abi(pkg, oracle, small):
+    """sann_heavy_rank: the legacy source for a BATCH in one C-ABI call -- light rank, then HeavyRanker.rank +
+    sortBy(-score) + take(maxNumResults) (SimClustersANNCandidateSource.scala:182-200, HeavyRanker.scala:28-69) fused behind it
+    on the device -- against the composition of the operator oracle and the pair-score oracle: several queries, a tweet source,
+    candidates without an embedding (None: dropped), a source id the store does not hold (every pair None: empty result),
+    three ranking algorithms, and the light ranking alone."""
+    co, offs, cids, scs = small
+    rs = pkg.representation_scorer
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores, n_partitions=8)
+    rng = np.random.default_rng(9)
+    nq = 5
+    embs = [[(int(c), float(s)) for c, s in zip(cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]])] for q in range(nq)]
+    src_tweets = [None, int(co.tweet_ids[5]), None, None, int(co.tweet_ids[77])]
+    sids = [100, 101, 102, 999, 104]  # 999 is not in the source store
+    src_store = rs.EmbeddingStore({sids[q]: embs[q] for q in range(nq) if sids[q] != 999})
+    for ranking, heavy_min in ((2, 0.05), (6, 0.01), (1, 0.0)):
+        lcfg = pkg.LegacySimClustersANNConfig(maxNumResults=40, maxTweetCandidateAgeHours=175200, minScore=heavy_min, enableHeavyRanking=True,
+                                              rankingAlgorithm=ranking, maxReRankingCandidates=250, maxTopTweetsPerCluster=200, maxScanClusters=40)
+        light_alg = pkg.ScoringAlgorithm.LogCosineSimilarity if ranking == 6 else pkg.ScoringAlgorithm.CosineSimilarity
+        ocfg = pkg.SimClustersANNConfig(maxNumResults=250, maxTopTweetsPerCluster=200, maxScanClusters=40, maxTweetCandidateAgeHours=175200,
+                                        annAlgorithm=light_alg)
+        lights, tweets = [], {}
+        for q in range(nq):
+            l_ids, _, _ = oracle.sann_query([c for c, _ in embs[q]], [s for _, s in embs[q]], src_tweets[q], ocfg, co.now_ms, co.cluster_ids,
+                                            co.list_offsets, co.tweet_ids, co.scores, variant=3)
+            lights.append(l_ids)
+            for t in l_ids.tolist():
+                if t not in tweets and rng.random() < 0.85:
+                    n = int(rng.integers(1, 12))
+                    pool = cids[offs[q]:offs[q + 1]]
+                    tweets[t] = [(int(c), float(s)) for c, s in zip(rng.choice(pool, min(n, len(pool)), replace=False), rng.random(n) + 0.05)]
+        tw_store = rs.EmbeddingStore(tweets)
+        source = pkg.LegacySimClustersANNCandidateSource(index, src_store, tw_store, now_ms=co.now_ms)
+        e_o = np.zeros(nq + 1, np.int64)
+        e_o[1:] = np.cumsum([len(e) for e in embs])
+        ids, sc, cnt = source.get_batch(e_o, np.concatenate([[c for c, _ in e] for e in embs]).astype(np.int32),
+                                        np.concatenate([[s for _, s in e] for e in embs]), lcfg, source_tweet_ids=src_tweets, source_internal_ids=sids)
+        for q in range(nq):
+            want = []
+            if sids[q] != 999:
+                se = rs.simclusters_embedding(embs[q])
+                for t in lights[q].tolist():
+                    if t in tweets:
+                        te = rs.simclusters_embedding(tweets[t])
+                        s = oracle.pair_score(ranking, se[0], se[1], te[0], te[1])
+                        if s >= lcfg.minScore:
+                            want.append((t, s))
+            want.sort(key=lambda x: (-x[1], x[0]))
+            want = want[:40]
+            assert cnt[q] == len(want), (ranking, q, cnt[q], len(want))
+            assert ids[q, :cnt[q]].tolist() == [t for t, _ in want]
+            assert np.array_equal(sc[q, :cnt[q]].view(np.int64), np.array([s for _, s in want]).view(np.int64))
+        assert cnt[3] == 0 and cnt[0] == 40
+        tw_store.close()
+    # without heavy ranking the stores are not needed: the light ranking of every query, cut at maxNumResults
+    lcfg2 = pkg.LegacySimClustersANNConfig(maxNumResults=60, maxTweetCandidateAgeHours=175200, rankingAlgorithm=6, maxTopTweetsPerCluster=200,
+                                           maxScanClusters=40)
+    ocfg2 = pkg.SimClustersANNConfig(maxNumResults=60, maxTopTweetsPerCluster=200, maxScanClusters=40, maxTweetCandidateAgeHours=175200,
+                                     annAlgorithm=pkg.ScoringAlgorithm.LogCosineSimilarity)
+    ids, sc, cnt = pkg.LegacySimClustersANNCandidateSource(index, now_ms=co.now_ms).get_batch(
+        e_o, np.concatenate([[c for c, _ in e] for e in embs]).astype(np.int32), np.concatenate([[s for _, s in e] for e in embs]), lcfg2,
+        source_tweet_ids=src_tweets)
+    for q in range(nq):
+        l_ids, l_sc, _ = oracle.sann_query([c for c, _ in embs[q]], [s for _, s in embs[q]], src_tweets[q], ocfg2, co.now_ms, co.cluster_ids,
+                                           co.list_offsets, co.tweet_ids, co.scores, variant=3)
+        assert cnt[q] == len(l_ids) and np.array_equal(ids[q, :cnt[q]], l_ids) and np.array_equal(sc[q, :cnt[q]].view(np.int64), l_sc.view(np.int64))
+    # argument errors
+    with pytest.raises(ValueError):
+        pkg.LegacySimClustersANNCandidateSource(index, now_ms=co.now_ms).get_batch(e_o, np.zeros(e_o[-1], np.int32), np.ones(e_o[-1]),
+                                                                                   pkg.LegacySimClustersANNConfig(enableHeavyRanking=True))
+    src_store.close(); index.close()

@@ -164,6 +164,83 @@ __global__ __launch_bounds__(256) void rsx_group_kernel(GroupArgs g) {
   g.out_max[i] = mx;
 }
 
+// ---- the heavy-rank step of the legacy candidate source, one workgroup per query -------------------------------------------
+// HeavyRanker.UniformScoreStoreRanker.rank (src/scala/com/twitter/simclusters_v2/candidate_source/HeavyRanker.scala:28-69) +
+// reranking's sort and cut (SimClustersANNCandidateSource.scala:182-200): for the query's light candidates (at most 1024, already
+// cut at maxReRankingCandidates) the pair score of (source embedding, candidate tweet embedding) through the resident stores --
+// both hydrated by id HERE, a binary search in the store's device id column; a side the store does not hold is the
+// reference's None and drops the candidate -- kept if score >= minScore (:63), sorted by score descending (ties, which the
+// reference leaves to Map iteration order under a stable sort: tweet id ascending), cut at maxNumResults.
+__device__ inline int store_row(const int64_t *ids, int n, int64_t id) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (ids[mid] < id) lo = mid + 1;
+    else hi = mid;
+  }
+  return (lo < n && ids[lo] == id) ? lo : -1;
+}
+constexpr int HR_MAX = 1024;  // light candidates per query (MaxNumResultsUpperBound is 1000)
+__global__ __launch_bounds__(256) void rsx_heavy_rank_kernel(int alg, StoreView S, const int64_t *s_ids, int n_s, StoreView T,
+                                                             const int64_t *t_ids, int n_t, const int64_t *source_ids,
+                                                             const int64_t *light_ids, const int32_t *light_counts, int light_stride,
+                                                             double min_score, int k, int out_stride, int64_t *out_ids,
+                                                             double *out_scores, int32_t *out_counts) {
+  __shared__ uint64_t s_hi[HR_MAX], s_lo[HR_MAX];
+  __shared__ int s_n;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int count = min(light_counts[q], min(light_stride, HR_MAX));
+  const int rs = store_row(s_ids, n_s, source_ids[q]);  // (uniform)
+  if (tid == 0) s_n = 0;
+  int np = 64;
+  while (np < count) np <<= 1;
+  __syncthreads();
+  int mine = 0;
+  for (int j = tid; j < np; j += 256) {
+    uint64_t hi = 0ull, lo = 0ull;
+    if (j < count && rs >= 0) {
+      const int64_t id = light_ids[(int64_t)q * light_stride + j];
+      const int rt = store_row(t_ids, n_t, id);
+      if (rt >= 0) {
+        const int64_t a0 = S.off[rs], b0 = T.off[rt];
+        const double v = pair_score(alg, S.cid + a0, S.sc + a0, (int)(S.off[rs + 1] - a0), T.cid + b0, T.sc + b0, (int)(T.off[rt + 1] - b0));
+        if (v >= min_score) {  // HeavyRanker.scala:63 (false for NaN)
+          hi = sann::score_key(v);
+          lo = sann::id_key(id);
+          mine++;
+        }
+      }
+    }
+    s_hi[j] = hi;
+    s_lo[j] = lo;
+  }
+  if (mine) atomicAdd(&s_n, mine);
+  __syncthreads();
+  // bitonic sort of np 128-bit keys, descending (empty slots are (0, 0): below every real key)
+  for (int kk = 2; kk <= np; kk <<= 1) {
+    for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+      for (int i = tid; i < np; i += 256) {
+        const int l = i ^ jj;
+        if (l > i) {
+          const uint64_t ah = s_hi[i], al = s_lo[i], bh = s_hi[l], bl = s_lo[l];
+          const bool a_lt_b = ah < bh || (ah == bh && al < bl);
+          const bool desc = (i & kk) == 0;
+          if (desc ? a_lt_b : !a_lt_b && !(ah == bh && al == bl)) {
+            s_hi[i] = bh; s_lo[i] = bl; s_hi[l] = ah; s_lo[l] = al;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int n_out = min(s_n, max(k, 0));
+  for (int i = tid; i < n_out; i += 256) {
+    out_ids[(int64_t)q * out_stride + i] = sann::key_id(s_lo[i]);
+    out_scores[(int64_t)q * out_stride + i] = sann::key_score(s_hi[i]);
+  }
+  if (tid == 0) out_counts[q] = n_out;
+}
+
 struct Buf {
   void *p = nullptr;
   ~Buf() { if (p) (void)hipFree(p); }
@@ -180,6 +257,7 @@ struct rsx_store {
   int device = 0;
   std::vector<int64_t> ids;  // ascending; row = position
   Buf off, cid, sc;
+  Buf d_ids;  // the ids on the device (hydration by id inside a kernel: rsx_heavy_rank_device)
   StoreView view() const { return StoreView{(const int64_t *)off.p, (const int32_t *)cid.p, (const double *)sc.p}; }
   int32_t row_of(int64_t id) const {
     auto it = std::lower_bound(ids.begin(), ids.end(), id);
@@ -301,6 +379,7 @@ int rsx_store_build(int32_t device, int64_t n, const int64_t *ids, const int64_t
   RSX_TRY(st->off.put(n ? offsets : &zero, ((size_t)n + 1) * 8));
   RSX_TRY(st->cid.put(cluster_ids, (size_t)total * 4));
   RSX_TRY(st->sc.put(scores, (size_t)total * 8));
+  RSX_TRY(st->d_ids.put(ids, (size_t)n * 8));
   *out = st.release();
   return RSX_OK;
 } ABI_CATCH
@@ -335,6 +414,33 @@ int rsx_store_list_scores(const rsx_store_t *targets, const rsx_store_t *candida
   std::vector<int32_t> ra((size_t)n_candidates, targets->row_of(target_id)), rb((size_t)n_candidates);
   for (int32_t i = 0; i < n_candidates; i++) rb[(size_t)i] = candidates->row_of(candidate_ids[i]);
   return rows_scores(targets, candidates, algorithm, n_candidates, ra, rb, out_scores, out_present);
+} ABI_CATCH
+
+int rsx_heavy_rank_device(const rsx_store_t *source_store, const rsx_store_t *tweet_store, void *hip_stream, int32_t algorithm,
+                          int32_t nq, const void *d_source_ids, const void *d_light_ids, const void *d_light_counts,
+                          int32_t light_stride, double min_score, int32_t max_num_results, int32_t out_stride, void *d_out_ids,
+                          void *d_out_scores, void *d_out_counts) try {
+  if (!source_store || !tweet_store || nq < 0) return rsx_fail(RSX_EINVAL, "NULL store or nq < 0");
+  if (algorithm < 1 || algorithm > 7) return rsx_fail(RSX_EINVAL, "unknown pair scoring algorithm");
+  if (source_store->device != tweet_store->device) return rsx_fail(RSX_EINVAL, "stores live on different devices");
+  if (light_stride < 1 || out_stride < 1 || max_num_results > out_stride) return rsx_fail(RSX_EINVAL, "bad strides");
+  if (nq == 0) return RSX_OK;
+  if (!d_source_ids || !d_light_ids || !d_light_counts || !d_out_ids || !d_out_scores || !d_out_counts)
+    return rsx_fail(RSX_EINVAL, "NULL device pointer");
+  RSX_TRY(hipSetDevice(source_store->device));
+  hipLaunchKernelGGL(rsx_heavy_rank_kernel, dim3(nq), dim3(256), 0, (hipStream_t)hip_stream, algorithm, source_store->view(),
+                     (const int64_t *)source_store->d_ids.p, (int)source_store->ids.size(), tweet_store->view(),
+                     (const int64_t *)tweet_store->d_ids.p, (int)tweet_store->ids.size(), (const int64_t *)d_source_ids,
+                     (const int64_t *)d_light_ids, (const int32_t *)d_light_counts, light_stride, min_score, max_num_results, out_stride,
+                     (int64_t *)d_out_ids, (double *)d_out_scores, (int32_t *)d_out_counts);
+  RSX_TRY(hipGetLastError());
+  return RSX_OK;
+} ABI_CATCH
+
+int rsx_store_device(const rsx_store_t *store, int32_t *device) try {
+  if (!store || !device) return rsx_fail(RSX_EINVAL, "NULL argument");
+  *device = store->device;
+  return RSX_OK;
 } ABI_CATCH
 
 int rsx_store_group_features(const rsx_store_t *candidates, int32_t algorithm, int32_t n_candidates,

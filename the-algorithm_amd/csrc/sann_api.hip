@@ -25,6 +25,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/representation_scorer.h"
 #include "../../include/simclusters_ann.h"
 #include "sann_host.h"
 #include "sann_kernels.h"
@@ -1802,6 +1803,102 @@ int sann_get_tweet_candidates_at(sann_index_t *index, int32_t variant, const int
   return sann_candidates_pooled(index, variant, nq > 0 ? now_ms[0] : 0, now_ms, nq, emb_offsets, emb_cluster_ids, emb_scores,
                                 source_tweet_ids, has_source_tweet, configs, n_configs, scan_offsets, scan_cluster_ids, out_ids,
                                 out_scores, out_stride, out_counts, out_map_sizes);
+} ABI_CATCH
+
+// The legacy candidate source for a batch: light rank + (optional) heavy rank, one call (see the header).  Runs on a pooled batch
+// object and stream of its own, outside the submission engine (whose jobs are plain getTweetCandidates calls).
+int sann_heavy_rank(sann_index_t *index, const struct rsx_store *source_store, const struct rsx_store *tweet_store, int64_t now_ms,
+                    int32_t nq, const int64_t *emb_offsets, const int32_t *emb_cluster_ids, const double *emb_scores,
+                    const int64_t *source_tweet_ids, const uint8_t *has_source_tweet, const int64_t *source_internal_ids,
+                    const sann_legacy_config_t *config, int64_t *out_ids, double *out_scores, int32_t out_stride,
+                    int32_t *out_counts) try {
+  if (!index || !config) return fail(SANN_EINVAL, "NULL argument");
+  if (nq < 0) return fail(SANN_EINVAL, "nq < 0");
+  const sann_legacy_config_t &c = *config;
+  const bool heavy = c.enable_heavy_ranking != 0;
+  if (heavy) {
+    if (!source_store || !tweet_store || (nq > 0 && !source_internal_ids)) return fail(SANN_EINVAL, "heavy ranking needs the source and tweet embedding stores and the source ids");
+    if (c.ranking_algorithm < 1 || c.ranking_algorithm > 7) return fail(SANN_EINVAL, "unknown ranking algorithm");
+    if (c.max_reranking_candidates < 0 || c.max_reranking_candidates > 1000) return fail(SANN_ELIMIT, "max_reranking_candidates above 1000");
+    int32_t d1 = -1, d2 = -1;
+    if (rsx_store_device(source_store, &d1) != 0 || rsx_store_device(tweet_store, &d2) != 0 || d1 != index->device || d2 != index->device)
+      return fail(SANN_EINVAL, "the embedding stores must live on the index's device");
+  }
+  const int k_final = c.max_num_results < 0 ? 0 : c.max_num_results;
+  if (k_final > 1000) return fail(SANN_ELIMIT, "legacy variant: max_num_results above 1000");
+  if (nq > 0 && (out_stride < std::max(k_final, 1) || !out_ids || !out_scores || !out_counts)) return fail(SANN_EINVAL, "output arrays / out_stride");
+  if (nq == 0) return SANN_OK;
+  // SimClustersANNCandidateSource.scala:147-150,163-173: no normalisation, the "log" form (over l2norm), or the cosine form
+  sann_config_t light{};
+  light.max_num_results = heavy ? c.max_reranking_candidates : k_final;  // candidates.take(maxReRankingCandidates) / take(maxNumResults)
+  light.candidate_embedding_type = c.candidate_embedding_type;
+  light.min_score = 0.0;  // (ignored by the legacy variant)
+  light.max_top_tweets_per_cluster = c.max_top_tweets_per_cluster;
+  light.max_scan_clusters = c.max_scan_clusters;
+  light.max_tweet_candidate_age_hours = c.max_tweet_candidate_age_hours;
+  light.min_tweet_candidate_age_hours = c.min_tweet_candidate_age_hours;
+  light.ann_algorithm = !c.enable_partial_normalization ? SANN_ALG_DOT_PRODUCT : (c.ranking_algorithm == 6 ? SANN_ALG_LOG_COSINE : SANN_ALG_COSINE);
+  sann_batch *b = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(index->pool_mu);
+    if (!index->pool.empty()) {
+      b = index->pool.back();
+      index->pool.pop_back();
+    }
+  }
+  HIP_TRY(hipSetDevice(index->device));
+  if (!b) {
+    b = new (std::nothrow) sann_batch();
+    if (!b) return fail(SANN_ENOMEM, "out of host memory");
+    b->ix = index;
+  }
+  int rc = SANN_OK;
+  if (!b->own_stream && hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(SANN_EDEVICE, "hipStreamCreateWithFlags");
+  hipStream_t st = b->own_stream;
+  b->variant = SANN_VARIANT_LEGACY;
+  DevBuf d_src, d_ids, d_sc, d_cnt;
+  if (rc == SANN_OK)
+    rc = batch_reset(b, st, now_ms, nq, emb_offsets, emb_cluster_ids, emb_scores, source_tweet_ids, has_source_tweet, &light, 1, nullptr, nullptr);
+  if (rc == SANN_OK) rc = sann_batch_run(b, st);
+  if (rc == SANN_OK) rc = sann_batch_finish(b, st);  // (exact light lists first: the slow tail, if any, has run)
+  if (rc == SANN_OK && !heavy) rc = results_impl(b, st, out_ids, out_scores, out_stride, out_counts, nullptr);
+  if (rc == SANN_OK && heavy) {
+    const int ks = std::max(k_final, 1);
+    auto dev = [&](hipError_t e, const char *what) { if (e != hipSuccess && rc == SANN_OK) rc = fail(SANN_EDEVICE, std::string(what) + ": " + hipGetErrorString(e)); };
+    dev(d_src.reserve((size_t)nq * 8), "hipMalloc");
+    dev(d_ids.reserve((size_t)nq * ks * 8), "hipMalloc");
+    dev(d_sc.reserve((size_t)nq * ks * 8), "hipMalloc");
+    dev(d_cnt.reserve((size_t)nq * 4), "hipMalloc");
+    if (rc == SANN_OK) dev(hipMemcpyAsync(d_src.p, source_internal_ids, (size_t)nq * 8, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+    if (rc == SANN_OK) {
+      BatchView bv = b->view();
+      if (rsx_heavy_rank_device(source_store, tweet_store, st, c.ranking_algorithm, nq, d_src.p, bv.out_ids, bv.out_counts, b->stride,
+                                c.min_score, k_final, ks, d_ids.p, d_sc.p, d_cnt.p) != 0)
+        rc = fail(SANN_EDEVICE, std::string("heavy rank: ") + rsx_last_error());
+    }
+    if (rc == SANN_OK) {
+      const size_t row = (size_t)ks * 8;
+      dev(hipMemcpy2DAsync(out_ids, (size_t)out_stride * 8, d_ids.p, row, row, (size_t)nq, hipMemcpyDeviceToHost, st), "hipMemcpy2DAsync");
+      dev(hipMemcpy2DAsync(out_scores, (size_t)out_stride * 8, d_sc.p, row, row, (size_t)nq, hipMemcpyDeviceToHost, st), "hipMemcpy2DAsync");
+      dev(hipMemcpyAsync(out_counts, d_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+      dev(hipStreamSynchronize(st), "hipStreamSynchronize");
+    }
+  }
+  std::string keep = g_err;
+  bool pooled = false;
+  if (rc == SANN_OK || rc == SANN_EINVAL || rc == SANN_ELIMIT) {
+    std::lock_guard<std::mutex> lk(index->pool_mu);
+    if (index->pool.size() < 16) {
+      index->pool.push_back(b);
+      pooled = true;
+    }
+  }
+  if (!pooled) {
+    (void)hipStreamSynchronize(st);
+    delete b;
+  }
+  if (rc != SANN_OK) g_err = keep;
+  return rc;
 } ABI_CATCH
 
 int sann_host_alloc(int64_t bytes, void **out) try {

@@ -162,3 +162,55 @@ JNIEXPORT jint JNICALL Java_com_twitter_simclustersann_gpu_SannJni_getTweetCandi
   if (rc != SANN_OK) throw_runtime(env, sann_last_error());
   return rc;
 }
+
+
+/* int heavyRank0(long index, long sourceStore, long tweetStore, long nowMs, int nq, ByteBuffer embOffsets, embClusterIds, embScores,
+ *                sourceTweetIds, hasSourceTweet, sourceInternalIds, legacyConfig /+ one sann_legacy_config_t, 48 bytes +/,
+ *                outIds, outScores, int outStride, outCounts)
+ * = the legacy in-process source for nq queries: fetchCandidates + reranking with the heavy rank fused behind the light one
+ * (SimClustersANNCandidateSource.scala:107-200, HeavyRanker.scala:28-69).  sourceStore / tweetStore are RsxJni store handles
+ * (0 when the config has no heavy ranking). */
+JNIEXPORT jint JNICALL Java_com_twitter_simclustersann_gpu_SannJni_heavyRank0(
+    JNIEnv *env, jclass cls, jlong index, jlong sourceStore, jlong tweetStore, jlong nowMs, jint nq, jobject embOffsets, jobject embClusterIds,
+    jobject embScores, jobject sourceTweetIds, jobject hasSourceTweet, jobject sourceInternalIds, jobject legacyConfig, jobject outIds,
+    jobject outScores, jint outStride, jobject outCounts) {
+  (void)cls;
+#define BUF(x) ((x) ? (*env)->GetDirectBufferAddress(env, (x)) : NULL)
+#define CAP(x) ((*env)->GetDirectBufferCapacity(env, (x)))
+  if (!embOffsets || !legacyConfig || !outIds || !outScores || !outCounts) {
+    throw_runtime(env, "a required direct buffer is null");
+    return SANN_EINVAL;
+  }
+  if (nq < 0 || outStride < 1) {
+    throw_runtime(env, "nq >= 0 and outStride >= 1");
+    return SANN_EINVAL;
+  }
+  if (CAP(legacyConfig) < (jlong)sizeof(sann_legacy_config_t) || CAP(outIds) < (jlong)nq * outStride * 8 || CAP(outScores) < (jlong)nq * outStride * 8 ||
+      CAP(outCounts) < (jlong)nq * 4 || CAP(embOffsets) < ((jlong)nq + 1) * 8 || (sourceTweetIds && CAP(sourceTweetIds) < (jlong)nq * 8) ||
+      (hasSourceTweet && CAP(hasSourceTweet) < (jlong)nq) || (sourceInternalIds && CAP(sourceInternalIds) < (jlong)nq * 8)) {
+    throw_runtime(env, "a direct buffer is smaller than the batch needs");
+    return SANN_EINVAL;
+  }
+  if ((sourceTweetIds == NULL) != (hasSourceTweet == NULL)) {
+    throw_runtime(env, "sourceTweetIds / hasSourceTweet come as a pair");
+    return SANN_EINVAL;
+  }
+  {
+    const int64_t *eo = (const int64_t *)BUF(embOffsets);
+    const int64_t e0 = nq ? eo[0] : 0, e1 = nq ? eo[nq] : 0;
+    if (e0 < 0 || e1 < e0 || (e1 > e0 && (!embClusterIds || !embScores || CAP(embClusterIds) < e1 * 4 || CAP(embScores) < e1 * 8))) {
+      throw_runtime(env, "embClusterIds / embScores are smaller than embOffsets says");
+      return SANN_EINVAL;
+    }
+  }
+  const int rc = sann_heavy_rank((sann_index_t *)(intptr_t)index, (const struct rsx_store *)(intptr_t)sourceStore,
+                                 (const struct rsx_store *)(intptr_t)tweetStore, nowMs, nq, (const int64_t *)BUF(embOffsets),
+                                 (const int32_t *)BUF(embClusterIds), (const double *)BUF(embScores), (const int64_t *)BUF(sourceTweetIds),
+                                 (const uint8_t *)BUF(hasSourceTweet), (const int64_t *)BUF(sourceInternalIds),
+                                 (const sann_legacy_config_t *)BUF(legacyConfig), (int64_t *)BUF(outIds), (double *)BUF(outScores), outStride,
+                                 (int32_t *)BUF(outCounts));
+#undef CAP
+#undef BUF
+  if (rc != SANN_OK) throw_runtime(env, sann_last_error());
+  return rc;
+}

@@ -195,6 +195,8 @@ _PROTOS = {
     "sann_poll": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
     "sann_batcher_get_tweet_candidates": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sann_batcher_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sann_heavy_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "sann_debug_call_trace": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "sann_debug_normalise": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
     "sann_debug_wave_sort": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p]),
@@ -582,6 +584,13 @@ def pinned_array(shape, dtype) -> np.ndarray:
     return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 
+class sann_legacy_config_t(C.Structure):
+    _fields_ = [("max_num_results", C.c_int32), ("max_tweet_candidate_age_hours", C.c_int32), ("min_tweet_candidate_age_hours", C.c_int32),
+                ("candidate_embedding_type", C.c_int32), ("min_score", C.c_double), ("enable_partial_normalization", C.c_int32),
+                ("enable_heavy_ranking", C.c_int32), ("ranking_algorithm", C.c_int32), ("max_reranking_candidates", C.c_int32),
+                ("max_top_tweets_per_cluster", C.c_int32), ("max_scan_clusters", C.c_int32)]
+
+
 class sann_batcher_options_t(C.Structure):
     _fields_ = [("variant", C.c_int32), ("max_batch", C.c_int32), ("max_wait_us", C.c_int32), ("n_dispatchers", C.c_int32)]
 
@@ -769,28 +778,41 @@ class LegacySimClustersANNCandidateSource:
             source_internal_id: Optional[int] = None, now_ms: Optional[int] = None) -> List[Tuple[int, float]]:
         """sourceEmbeddingId: tweet id when the source is a tweet (parseTweetId), else None.
         source_internal_id: the id the heavy ranker looks the source embedding up under."""
-        from . import representation_scorer as rs
-
-        if not config.enablePartialNormalization:
-            alg = ScoringAlgorithm.DotProduct
-        elif int(config.rankingAlgorithm) == self.LOG_COSINE:
-            alg = ScoringAlgorithm.LogCosineSimilarity
-        else:
-            alg = ScoringAlgorithm.CosineSimilarity
-        light_k = config.maxReRankingCandidates if config.enableHeavyRanking else config.maxNumResults
-        cfg = SimClustersANNConfig(maxNumResults=light_k, minScore=0.0, candidateEmbeddingType=config.candidateEmbeddingType,
-                                   maxTopTweetsPerCluster=config.maxTopTweetsPerCluster, maxScanClusters=config.maxScanClusters,
-                                   maxTweetCandidateAgeHours=config.maxTweetCandidateAgeHours,
-                                   minTweetCandidateAgeHours=config.minTweetCandidateAgeHours, annAlgorithm=alg)
-        light = ApproximateCosineSimilarity(self.index, Variant.legacy, self.now_ms).apply(
-            sourceEmbedding, sourceEmbeddingId, cfg, now_ms=now_ms)
-        if not config.enableHeavyRanking:
-            return light[:max(config.maxNumResults, 0)]
-        if self.source_store is None or self.tweet_store is None:
-            raise ValueError("heavy ranking needs the source and tweet embedding stores")
+        emb = list(sourceEmbedding)
+        offs = np.array([0, len(emb)], np.int64)
         sid = source_internal_id if source_internal_id is not None else sourceEmbeddingId
-        ids = [t for t, _ in light]
-        scores = rs.list_scores(rs.ScoringAlgorithm(int(config.rankingAlgorithm)), self.source_store, self.tweet_store, sid, ids)
-        ranked = [(t, s) for t, s in zip(ids, scores) if s is not None and s >= config.minScore]
-        ranked.sort(key=lambda x: (-x[1], x[0]))
-        return ranked[:max(config.maxNumResults, 0)]
+        ids, sc, cnt = self.get_batch(offs, np.array([c for c, _ in emb], np.int32), np.array([s for _, s in emb], np.float64), config,
+                                      source_tweet_ids=None if sourceEmbeddingId is None else [sourceEmbeddingId],
+                                      source_internal_ids=[sid if sid is not None else 0], now_ms=now_ms)
+        return list(zip(ids[0, :cnt[0]].tolist(), sc[0, :cnt[0]].tolist()))
+
+    def get_batch(self, emb_offsets, emb_cluster_ids, emb_scores, config: LegacySimClustersANNConfig, *, source_tweet_ids=None,
+                  source_internal_ids=None, now_ms: Optional[int] = None):
+        """sann_heavy_rank: the whole legacy source for a batch of queries in one call -- light rank and (config.enableHeavyRanking)
+        the heavy rank fused behind it on the device.  source_tweet_ids: per query a tweet id or None.  Returns
+        (ids [nq, k], scores [nq, k], counts [nq])."""
+        if config.enableHeavyRanking and (self.source_store is None or self.tweet_store is None):
+            raise ValueError("heavy ranking needs the source and tweet embedding stores")
+        lib = load_library()
+        eo = np.ascontiguousarray(emb_offsets, np.int64)
+        ec = np.ascontiguousarray(emb_cluster_ids, np.int32)
+        es = np.ascontiguousarray(emb_scores, np.float64)
+        nq = len(eo) - 1
+        src = has = None
+        if source_tweet_ids is not None:
+            src = np.array([0 if t is None else t for t in source_tweet_ids], np.int64)
+            has = np.array([0 if t is None else 1 for t in source_tweet_ids], np.uint8)
+        sid = np.ascontiguousarray(source_internal_ids if source_internal_ids is not None else np.zeros(nq), np.int64)
+        c = sann_legacy_config_t(config.maxNumResults, config.maxTweetCandidateAgeHours, config.minTweetCandidateAgeHours,
+                                 config.candidateEmbeddingType, config.minScore, int(config.enablePartialNormalization),
+                                 int(config.enableHeavyRanking), int(config.rankingAlgorithm), config.maxReRankingCandidates,
+                                 config.maxTopTweetsPerCluster, config.maxScanClusters)
+        k = max(1, config.maxNumResults)
+        ids, sc, cnt = np.zeros((nq, k), np.int64), np.zeros((nq, k), np.float64), np.zeros(nq, np.int32)
+        now = self.now_ms if now_ms is None else now_ms
+        if now is None:
+            raise ValueError("now_ms is required (Time.now is an explicit input)")
+        _check(lib.sann_heavy_rank(self.index.handle, None if self.source_store is None else self.source_store._h,
+                                   None if self.tweet_store is None else self.tweet_store._h, int(now), nq, _ptr(eo), _ptr(ec), _ptr(es),
+                                   _ptr(src), _ptr(has), _ptr(sid), C.byref(c), _ptr(ids), _ptr(sc), k, _ptr(cnt)))
+        return ids, sc, cnt
