@@ -480,6 +480,35 @@ int sann_exchange_to_owners(sann_comm_t *comm, void *hip_stream, const void *d_s
 int sann_owner_message_layout(int32_t queries_per_owner, int32_t stride, int64_t *chunk_bytes, int64_t *off_scores,
                               int64_t *off_counts, int64_t *off_map_sizes);
 
+/*
+ * The CLUSTER-ID-RANGE deployment north_star names: GPU g holds the WHOLE lists of the
+ * clusters in its range (an ordinary index, n_shards = 1), so a candidate's score terms are spread over GPUs.  The exact way
+ * to bring them together is to move postings, not partial sums: per batch every GPU sends the top-M prefix of each list the
+ * batch scans to the GPU hash(tweet id) % N names, the receiver builds a temporary index of ITS tweets' postings and runs the
+ * ordinary pipeline on it, and the owners merge as in the tweet-hash deployment (sann_exchange_to_owners +
+ * sann_merge_shards[_cut]; ComposedQueryable, ann/.../common/ShardApi.scala:71-87).  The pieces:
+ *   sann_index_export_prefix_counts      counts[cluster][dest] of the prefixes (rank < M) of the listed clusters, on the device
+ *   sann_index_export_prefixes_device    the postings themselves into d_out, segment (cluster, dest) at segment_offsets (in postings,
+ *                                        caller-computed from the counts: destination-major, clusters ascending), in rank order
+ *   sann_exchange_postings_by_tweet_hash grouped ncclSend / ncclRecv with per-peer counts (both sides know them)
+ *   sann_index_build_from_device_postings  the receiver's temporary index from device-resident lists, list order kept
+ * All queries of such a batch share one maxTopTweetsPerCluster (the prefix that travels).  Clusters the index does not hold
+ * count zero.  bench.py --sharding cluster-range drives them; tests/test_cluster_range_gpu.py does with logical shards.
+ */
+int sann_index_export_prefix_counts(sann_index_t *index, void *hip_stream, int32_t n_clusters, const int32_t *clusters, int32_t M,
+                                    int32_t n_ranks, int32_t *counts /* host, [n_clusters][n_ranks] */);
+int sann_index_export_prefixes_device(sann_index_t *index, void *hip_stream, int32_t n_clusters, const int32_t *clusters, int32_t M,
+                                      int32_t n_ranks, const int64_t *segment_offsets /* host, [n_clusters][n_ranks] */, void *d_out);
+int sann_exchange_postings_by_tweet_hash(sann_comm_t *comm, void *hip_stream, const void *d_send, const int64_t *send_counts /* [world] postings */,
+                                         void *d_recv, const int64_t *recv_counts);
+int sann_index_build_from_device_postings(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
+                                          const int64_t *list_offsets /* host CSR, in postings */, const void *d_postings, sann_index_t **out);
+/* Device memory for callers that do not link the HIP runtime themselves (staging buffers of the exchange above). */
+int sann_device_alloc(int32_t device, int64_t bytes, void **out);
+int sann_device_free(int32_t device, void *p);
+/* dst / src: device or host pointers (the runtime sorts out which); synchronous. */
+int sann_device_copy(int32_t device, void *dst, const void *src, int64_t bytes);
+
 /* Make the merge kernel write the final results into caller-owned device buffers (e.g. torch
  * tensors that feed an all-gather) instead of the batch's own; pass four NULLs to unbind.
  * Sizes: int64[nq*stride], double[nq*stride], int32[nq], int32[nq], stride as reported by

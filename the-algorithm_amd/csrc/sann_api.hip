@@ -1449,6 +1449,27 @@ int32_t sann_tweet_partition(int64_t tweet_id, int32_t n_partitions) {
   return n_partitions <= 1 ? 0 : (int32_t)tweet_partition(mix64((uint64_t)tweet_id), (uint32_t)n_partitions);
 }
 
+int sann_device_alloc(int32_t device, int64_t bytes, void **out) try {
+  if (!out || bytes < 0) return fail(SANN_EINVAL, "bad arguments");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMalloc(out, (size_t)std::max<int64_t>(bytes, 16)));
+  return SANN_OK;
+} ABI_CATCH
+int sann_device_free(int32_t device, void *p) try {
+  if (!p) return SANN_OK;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipFree(p));
+  return SANN_OK;
+} ABI_CATCH
+int sann_device_copy(int32_t device, void *dst, const void *src, int64_t bytes) try {
+  if (bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(SANN_EINVAL, "bad arguments");
+  if (bytes == 0) return SANN_OK;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDefault));
+  return SANN_OK;
+} ABI_CATCH
+
 int sann_device_synchronize(int32_t device) try {
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipDeviceSynchronize());

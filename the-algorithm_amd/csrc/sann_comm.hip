@@ -105,6 +105,32 @@ int sann_exchange_to_owners(sann_comm_t *c, void *hip_stream, const void *d_send
   return SANN_OK;
 } ABI_CATCH
 
+// The cluster-id-range deployment's exchange: postings (16 bytes each) to the GPU their tweet hashes to -- a grouped ncclSend /
+// ncclRecv round with a different count per peer; both sides know the counts (they were exchanged as a fixed-size block first).
+int sann_exchange_postings_by_tweet_hash(sann_comm_t *c, void *hip_stream, const void *d_send, const int64_t *send_counts, void *d_recv,
+                                         const int64_t *recv_counts) try {
+  if (!c || !send_counts || !recv_counts) return fail(SANN_EINVAL, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  int64_t so = 0, ro = 0;
+  for (int peer = 0; peer < c->world; peer++)
+    if (send_counts[peer] < 0 || recv_counts[peer] < 0) return fail(SANN_EINVAL, "negative count");
+  NCCL_TRY(ncclGroupStart());
+  for (int peer = 0; peer < c->world; peer++) {
+    ncclResult_t a = ncclSuccess;
+    if (send_counts[peer] > 0) a = ncclSend((const char *)d_send + so * 16, (size_t)send_counts[peer] * 16, ncclUint8, peer, c->comm, st);
+    if (a == ncclSuccess && recv_counts[peer] > 0) a = ncclRecv((char *)d_recv + ro * 16, (size_t)recv_counts[peer] * 16, ncclUint8, peer, c->comm, st);
+    if (a != ncclSuccess) {
+      (void)ncclGroupEnd();
+      return fail(SANN_EDEVICE, std::string("ncclSend/ncclRecv: ") + ncclGetErrorString(a));
+    }
+    so += send_counts[peer];
+    ro += recv_counts[peer];
+  }
+  NCCL_TRY(ncclGroupEnd());
+  return SANN_OK;
+} ABI_CATCH
+
 int sann_owner_message_layout(int32_t queries_per_owner, int32_t stride, int64_t *chunk_bytes, int64_t *off_scores,
                               int64_t *off_counts, int64_t *off_map_sizes) try {
   if (queries_per_owner < 0 || stride < 1) return fail(SANN_EINVAL, "bad sizes");

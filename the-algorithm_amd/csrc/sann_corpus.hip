@@ -292,6 +292,82 @@ __global__ __launch_bounds__(256) void scatter_kernel(int P, int n_shards, int s
   }
 }
 
+// Lists that arrive already in list order (sann_index_build_from_device_postings): per cluster, the entries per partition.
+__global__ __launch_bounds__(256) void count_parts_kernel(int P, int n_shards, int shard_id, const uint32_t *bucket_off, const Posting *buckets,
+                                                          uint32_t *kept /*[C+1]*/, uint32_t *cnt_cp /*[C*P]*/) {
+  __shared__ unsigned s_cnt[256];
+  const int c = blockIdx.x + 1, tid = threadIdx.x;
+  const uint32_t base = bucket_off[c], k = bucket_off[c + 1] - base;
+  s_cnt[tid] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < k; i += 256) {
+    const uint64_t h = mix64((uint64_t)buckets[base + i].id);
+    if (tweet_shard(h, (uint32_t)n_shards) == (uint32_t)shard_id) atomicAdd(&s_cnt[tweet_partition(h, (uint32_t)P)], 1u);
+  }
+  __syncthreads();
+  if (tid == 0) kept[c] = k;
+  for (int p = tid; p < P; p += 256) cnt_cp[(int64_t)(c - 1) * P + p] = s_cnt[p];
+}
+
+// ---- the cluster-id-range deployment's sender side --------------------------------------
+// One workgroup per requested cluster row: the list's top-M prefix (its postings with rank < M; ranks are the positions of
+// ApproximateCosineSimilarity.scala:87, all present when the index holds whole lists) is laid out BY RANK in LDS -- so no sort
+// is needed --, every posting is routed to GPU tweet_shard(hash(tweet id), n_ranks), and the postings of each destination are
+// counted (write = 0) or written, in rank order, at seg_off[cluster][dest] of `out` (write = 1).
+constexpr int EXPORT_MAX = 4096;  // M the export handles (the index caps lists at 2000; maxTopTweetsPerCluster is 800 in production)
+__global__ __launch_bounds__(256) void export_prefix_kernel(IndexView ix, const int32_t *rows, int M, int n_ranks, int write,
+                                                            uint32_t *counts /*[n][n_ranks]*/, const int64_t *seg_off /*[n][n_ranks]*/,
+                                                            Posting *out) {
+  __shared__ Posting s_p[EXPORT_MAX];
+  __shared__ uint8_t s_dest[EXPORT_MAX];
+  __shared__ unsigned s_cnt[16];
+  __shared__ unsigned s_wave[4];
+  const int tid = threadIdx.x, c = blockIdx.x, row = rows[c];
+  if (tid < 16) s_cnt[tid] = 0;
+  for (int i = tid; i < EXPORT_MAX; i += 256) s_dest[i] = 255;
+  __syncthreads();
+  // the P sub-lists hold the list's postings with ascending ranks: walk each up to the first rank >= M
+  const int P = ix.P;
+  for (int p = 0; p < P; p++) {
+    const uint32_t b = ix.sub_offsets[(int64_t)row * P + p], e = ix.sub_offsets[(int64_t)row * P + p + 1];
+    for (uint32_t i = b + tid; i < e; i += 256) {
+      const uint32_t r = ix.ranks[i];
+      if (r < (uint32_t)M && r < (uint32_t)EXPORT_MAX) {
+        const Posting q = ix.postings[i];
+        s_p[r] = q;
+        s_dest[r] = (uint8_t)tweet_shard(mix64((uint64_t)q.id), (uint32_t)n_ranks);
+      }
+    }
+  }
+  __syncthreads();
+  const int n = M < EXPORT_MAX ? M : EXPORT_MAX;
+  if (!write) {
+    for (int i = tid; i < n; i += 256)
+      if (s_dest[i] != 255) atomicAdd(&s_cnt[s_dest[i]], 1u);
+    __syncthreads();
+    if (tid < n_ranks) counts[(int64_t)c * n_ranks + tid] = s_cnt[tid];
+    return;
+  }
+  // stable compaction per destination: ranks ascending within a destination's segment
+  for (int d = 0; d < n_ranks; d++) {
+    unsigned run = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+      const int i = i0 + tid;
+      const bool mine = i < n && s_dest[i] == (uint8_t)d;
+      const unsigned long long m = __ballot(mine);
+      const int lane = tid & 63, wv = tid >> 6;
+      if (lane == 0) s_wave[wv] = (unsigned)__popcll(m);
+      __syncthreads();
+      unsigned before = 0;
+      for (int w = 0; w < wv; w++) before += s_wave[w];
+      const unsigned total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+      if (mine) out[seg_off[(int64_t)c * n_ranks + d] + run + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = s_p[i];
+      run += total;
+      __syncthreads();
+    }
+  }
+}
+
 // inverse normal CDF (Acklam's rational approximation, |rel err| < 1.2e-9)
 double inv_norm_cdf(double p) {
   static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
@@ -615,6 +691,147 @@ int sann_index_build_from_postings(const sann_index_options_t *opts, int32_t n_l
   guard.p = nullptr;
   *out = ix;
   return SANN_OK;
+} ABI_CATCH
+
+// An index from lists that are ALREADY on the device and in list order (the cluster-id-range deployment's receiver: the
+// postings the other GPUs sent for this GPU's tweets).  Order inside a list is kept as given; position = rank.
+int sann_index_build_from_device_postings(const sann_index_options_t *opts, int32_t n_lists, const int32_t *cluster_ids,
+                                          const int64_t *list_offsets, const void *d_postings, sann_index_t **out) try {
+  if (!out) return fail(SANN_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (!opts) return fail(SANN_EINVAL, "opts is NULL");
+  if (n_lists < 0 || (n_lists > 0 && (!cluster_ids || !list_offsets))) return fail(SANN_EINVAL, "bad list arrays");
+  const int P = opts->n_partitions == 0 ? 32 : opts->n_partitions;
+  if (P < 1 || P > 128 || (P & (P - 1))) return fail(SANN_EINVAL, "n_partitions must be a power of two in [1,128]");
+  const int n_shards = opts->n_shards <= 0 ? 1 : opts->n_shards;
+  if (opts->shard_id < 0 || opts->shard_id >= n_shards) return fail(SANN_EINVAL, "shard_id out of range");
+  for (int32_t i = 1; i < n_lists; i++)
+    if (cluster_ids[i] <= cluster_ids[i - 1]) return fail(SANN_EINVAL, "cluster_ids must be ascending and unique");
+  const int C = n_lists;
+  const int64_t o0 = C ? list_offsets[0] : 0;
+  const int64_t total = C ? list_offsets[C] - o0 : 0;
+  int32_t max_len = 0;
+  for (int32_t r = 0; r < C; r++) {
+    const int64_t len = list_offsets[r + 1] - list_offsets[r];
+    if (len < 0) return fail(SANN_EINVAL, "list_offsets must be non-decreasing");
+    if (len > SORT_MAX) return fail(SANN_ELIMIT, "a list holds more than 4096 entries");
+    max_len = std::max<int32_t>(max_len, (int32_t)len);
+  }
+  if (total > 0xfffffff0ll) return fail(SANN_ELIMIT, "more than 2^32 postings");
+  if (total > 0 && !d_postings) return fail(SANN_EINVAL, "d_postings is NULL");
+  sann_index *ix = new (std::nothrow) sann_index();
+  if (!ix) return fail(SANN_ENOMEM, "out of host memory");
+  struct Guard { sann_index *p; ~Guard() { delete p; } } guard{ix};
+  ix->device = opts->device;
+  ix->P = P;
+  ix->log2P = 0;
+  while ((1 << ix->log2P) < P) ix->log2P++;
+  ix->shard_id = opts->shard_id;
+  ix->n_shards = n_shards;
+  ix->cluster_ids.assign(cluster_ids, cluster_ids + C);
+  ix->n_postings_total = total;
+  ix->max_list_len = max_len;
+  std::vector<uint32_t> boff((size_t)C + 2, 0);
+  for (int c = 1; c <= C; c++) boff[(size_t)c] = (uint32_t)(list_offsets[c - 1] - o0);
+  boff[(size_t)C + 1] = (uint32_t)total;
+  HIP_TRY(hipSetDevice(ix->device));
+  DevBuf d_boff, d_kept, d_cnt;
+  HIP_TRY(d_boff.alloc(boff.size() * 4));
+  HIP_TRY(d_kept.alloc(((size_t)C + 1) * 4));
+  HIP_TRY(d_cnt.alloc(std::max<size_t>((size_t)C * P, 1) * 4));
+  HIP_TRY(hipMemcpy(d_boff.p, boff.data(), boff.size() * 4, hipMemcpyHostToDevice));
+  const Posting *buckets = (const Posting *)d_postings + o0;
+  if (C > 0) {
+    hipLaunchKernelGGL(count_parts_kernel, dim3((unsigned)C), dim3(256), 0, 0, P, n_shards, ix->shard_id, d_boff.as<uint32_t>(), buckets,
+                       d_kept.as<uint32_t>(), d_cnt.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+  }
+  std::vector<uint32_t> cnt((size_t)C * P);
+  if (C > 0) HIP_TRY(hipMemcpy(cnt.data(), d_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+  ix->h_sub_offsets.resize((size_t)C * P + 1);
+  uint64_t tot = 0;
+  for (size_t i = 0; i < (size_t)C * P; i++) {
+    ix->h_sub_offsets[i] = (uint32_t)tot;
+    tot += cnt[i];
+  }
+  ix->h_sub_offsets[(size_t)C * P] = (uint32_t)tot;
+  ix->n_postings = (int64_t)tot;
+  HIP_TRY(ix->postings.alloc(std::max<uint64_t>(tot, 1) * sizeof(Posting)));
+  HIP_TRY(ix->ranks.alloc(std::max<uint64_t>(tot, 1) * 4));
+  HIP_TRY(ix->sub_offsets.alloc(ix->h_sub_offsets.size() * 4));
+  HIP_TRY(hipMemcpy(ix->sub_offsets.p, ix->h_sub_offsets.data(), ix->h_sub_offsets.size() * 4, hipMemcpyHostToDevice));
+  if (C > 0) {
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)C), dim3(256), 0, 0, P, n_shards, ix->shard_id, d_boff.as<uint32_t>(),
+                       d_kept.as<uint32_t>(), buckets, ix->sub_offsets.as<uint32_t>(), ix->postings.as<Posting>(), ix->ranks.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  guard.p = nullptr;
+  *out = ix;
+  return SANN_OK;
+} ABI_CATCH
+
+// The sender side: counts (write = 0: counts[n_clusters * n_ranks] on the host) or the postings themselves (write = 1: into d_out at
+// seg_offsets[cluster][dest], in postings).  Clusters the index does not hold count zero.
+static int export_prefixes(sann_index_t *ix, hipStream_t st, int32_t n_clusters, const int32_t *clusters, int32_t M, int32_t n_ranks,
+                           int write, int32_t *counts, const int64_t *seg_offsets, void *d_out) {
+  if (!ix) return fail(SANN_EINVAL, "index is NULL");
+  if (ix->n_shards != 1) return fail(SANN_EINVAL, "a cluster-range shard holds whole lists (n_shards = 1)");
+  if (n_clusters < 0 || (n_clusters > 0 && !clusters) || n_ranks < 1 || n_ranks > 16) return fail(SANN_EINVAL, "bad clusters / n_ranks (1..16)");
+  if (M < 0) M = 0;
+  if (M > EXPORT_MAX) return fail(SANN_ELIMIT, "maxTopTweetsPerCluster above 4096");
+  if (n_clusters == 0) return SANN_OK;
+  if ((!write && !counts) || (write && (!seg_offsets || !d_out))) return fail(SANN_EINVAL, "NULL output");
+  std::vector<int32_t> rows((size_t)n_clusters);
+  std::vector<int32_t> held;
+  held.reserve((size_t)n_clusters);
+  std::vector<int32_t> at((size_t)n_clusters, -1);  // cluster i -> position among the held ones
+  for (int32_t i = 0; i < n_clusters; i++) {
+    const int r = ix->row_of(clusters[i]);
+    if (r >= 0) {
+      at[(size_t)i] = (int32_t)held.size();
+      held.push_back(r);
+    }
+  }
+  if (!write) std::fill(counts, counts + (size_t)n_clusters * n_ranks, 0);
+  if (held.empty()) return SANN_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  const int n = (int)held.size();
+  DevBuf d_rows, d_counts, d_seg;
+  HIP_TRY(d_rows.alloc((size_t)n * 4));
+  HIP_TRY(hipMemcpyAsync(d_rows.p, held.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  if (!write) {
+    HIP_TRY(d_counts.alloc((size_t)n * n_ranks * 4));
+  } else {
+    std::vector<int64_t> seg((size_t)n * n_ranks);
+    for (int32_t i = 0; i < n_clusters; i++)
+      if (at[(size_t)i] >= 0)
+        for (int d = 0; d < n_ranks; d++) seg[(size_t)at[(size_t)i] * n_ranks + d] = seg_offsets[(size_t)i * n_ranks + d];
+    HIP_TRY(d_seg.alloc(seg.size() * 8));
+    HIP_TRY(hipMemcpy(d_seg.p, seg.data(), seg.size() * 8, hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(export_prefix_kernel, dim3((unsigned)n), dim3(256), 0, st, ix->view(), d_rows.as<int32_t>(), M, n_ranks, write,
+                     d_counts.as<uint32_t>(), d_seg.as<int64_t>(), (Posting *)d_out);
+  HIP_TRY(hipGetLastError());
+  if (!write) {
+    std::vector<uint32_t> h((size_t)n * n_ranks);
+    HIP_TRY(hipMemcpyAsync(h.data(), d_counts.p, h.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int32_t i = 0; i < n_clusters; i++)
+      if (at[(size_t)i] >= 0)
+        for (int d = 0; d < n_ranks; d++) counts[(size_t)i * n_ranks + d] = (int32_t)h[(size_t)at[(size_t)i] * n_ranks + d];
+  } else {
+    HIP_TRY(hipStreamSynchronize(st));  // (the temporaries above die here)
+  }
+  return SANN_OK;
+}
+int sann_index_export_prefix_counts(sann_index_t *index, void *hip_stream, int32_t n_clusters, const int32_t *clusters, int32_t M,
+                                    int32_t n_ranks, int32_t *counts) try {
+  return export_prefixes(index, (hipStream_t)hip_stream, n_clusters, clusters, M, n_ranks, 0, counts, nullptr, nullptr);
+} ABI_CATCH
+int sann_index_export_prefixes_device(sann_index_t *index, void *hip_stream, int32_t n_clusters, const int32_t *clusters, int32_t M,
+                                      int32_t n_ranks, const int64_t *segment_offsets, void *d_out) try {
+  return export_prefixes(index, (hipStream_t)hip_stream, n_clusters, clusters, M, n_ranks, 1, nullptr, segment_offsets, d_out);
 } ABI_CATCH
 
 int sann_synth_tweet_embeddings(int32_t device, const sann_synth_params_t *sp, int64_t t0, int32_t n, int32_t *counts,

@@ -99,9 +99,10 @@ def merge_cut_lists(ids: np.ndarray, scores: np.ndarray, counts: np.ndarray, k: 
 # pipeline (same kernels, same accumulation order) on that temporary tweet-hash shard; the per-shard answers are merged
 # exactly as in the tweet-hash deployment (ComposedQueryable, ann/.../common/ShardApi.scala:71-87).
 #
-# This module carries that out with logical shards on one GPU through the C ABI (index builds, batches); the exchange is
-# a host-side regrouping whose bytes are counted.  It is the reference point beside the tweet-hash deployment, not a
-# competitor: it re-partitions ~N x M x 16 B per distinct scanned cluster on EVERY batch.
+# RangeShard / ClusterRangeDeployment below drive the library's entry points for it (include/simclusters_ann.h:
+# sann_index_export_prefix_counts, sann_index_export_prefixes_device, sann_exchange_postings_by_tweet_hash,
+# sann_index_build_from_device_postings): everything that touches postings runs on the device.  It is the reference point beside
+# the tweet-hash deployment, not a competitor: it re-partitions ~N x M x 16 B per distinct scanned cluster on EVERY batch.
 # ---------------------------------------------------------------------------------------------------------------------
 def score_key(scores: np.ndarray) -> np.ndarray:
     """Monotone map double -> uint64 in java.lang.Double.compare order (csrc/sann_math.h score_key)."""
@@ -144,71 +145,154 @@ def _mix64(x: np.ndarray) -> np.ndarray:
     return x
 
 
+class RangeShard:
+    """One rank's part of the cluster-id-range deployment, through the C ABI (include/simclusters_ann.h): the sender side
+    (prefix counts, packed export) and the receiver side (temporary index over the postings that arrived, the ordinary batch on
+    it).  `exchange` is whatever moves device bytes between ranks: RCCL (sann_exchange_postings_by_tweet_hash) between
+    processes, a device-to-device copy between logical shards of one process."""
+
+    def __init__(self, pkg, index, rank: int, world: int, *, device: int = 0, n_partitions: int = 0):
+        self.pkg, self.index, self.rank, self.world, self.device, self.n_partitions = pkg, index, rank, world, device, n_partitions
+        self.lib = pkg.load_library()
+        self._bufs = []
+
+    def _alloc(self, n_bytes: int) -> int:
+        import ctypes as C
+        p = C.c_void_p()
+        rc = self.lib.sann_device_alloc(self.device, max(int(n_bytes), 16), C.byref(p))
+        assert rc == 0, self.lib.sann_last_error()
+        self._bufs.append(p.value)
+        return p.value
+
+    def free(self):
+        for p in self._bufs:
+            self.lib.sann_device_free(self.device, p)
+        self._bufs = []
+
+    def export_counts(self, clusters: np.ndarray, M: int) -> np.ndarray:
+        """counts[cluster][dest] of the top-M prefixes of `clusters` (the batch's scanned clusters, ascending; the ones this
+        shard does not hold count zero), computed on the device."""
+        import ctypes as C
+        c = np.ascontiguousarray(clusters, np.int32)
+        out = np.zeros((len(c), self.world), np.int32)
+        rc = self.lib.sann_index_export_prefix_counts(self.index.handle, None, len(c), c.ctypes.data_as(C.c_void_p), int(M), self.world,
+                                                      out.ctypes.data_as(C.c_void_p))
+        assert rc == 0, self.lib.sann_last_error()
+        return out
+
+    def export(self, clusters: np.ndarray, M: int, counts: np.ndarray):
+        """The postings, packed destination-major (clusters ascending inside a destination, ranks ascending inside a cluster)
+        in one device buffer: (device pointer, send_counts[world] in postings)."""
+        import ctypes as C
+        c = np.ascontiguousarray(clusters, np.int32)
+        per_dest = counts.sum(axis=0).astype(np.int64)
+        dest_base = np.concatenate([[0], np.cumsum(per_dest)])
+        seg = (dest_base[:-1][None, :] + np.concatenate([np.zeros((1, self.world), np.int64), np.cumsum(counts, axis=0)[:-1]])).astype(np.int64)
+        seg = np.ascontiguousarray(seg)
+        d_send = self._alloc(int(dest_base[-1]) * 16)
+        rc = self.lib.sann_index_export_prefixes_device(self.index.handle, None, len(c), c.ctypes.data_as(C.c_void_p), int(M), self.world,
+                                                        seg.ctypes.data_as(C.c_void_p), C.c_void_p(d_send))
+        assert rc == 0, self.lib.sann_last_error()
+        return d_send, per_dest
+
+    def build_received(self, clusters: np.ndarray, counts_to_me: np.ndarray, d_recv: int):
+        """The temporary index of this rank's tweets: clusters ascending (every cluster has ONE source rank, and the sources'
+        ranges ascend with the rank, so source-major arrival order IS ascending cluster order), lists in rank order."""
+        import ctypes as C
+        sa = self.pkg.simclusters_ann
+        keep = counts_to_me > 0
+        cl = np.ascontiguousarray(np.asarray(clusters, np.int32)[keep])
+        offs = np.ascontiguousarray(np.concatenate([[0], np.cumsum(counts_to_me[keep].astype(np.int64))]))
+        opts = sa.sann_index_options_t(self.device, self.n_partitions, 0, 1)
+        h = C.c_void_p()
+        rc = self.lib.sann_index_build_from_device_postings(C.byref(opts), len(cl), cl.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p),
+                                                            C.c_void_p(d_recv), C.byref(h))
+        assert rc == 0, self.lib.sann_last_error()
+        ix = sa.ClusterTweetIndex.__new__(sa.ClusterTweetIndex)
+        ix._h, ix.device, ix.cluster_ids, ix.list_offsets = h, self.device, cl, offs
+        return ix
+
+
 class ClusterRangeDeployment:
-    """N logical cluster-range shards on one GPU (see the block comment above)."""
+    """N cluster-range shards as LOGICAL shards on one GPU, every step through the library's entry points (the same calls
+    bench.py --sharding cluster-range makes with one process per GPU): device-side export of the scanned lists' top-M prefixes,
+    the exchange (here a device-to-device regrouping; between processes sann_exchange_postings_by_tweet_hash over RCCL), the
+    device-side re-partition into a temporary index, the ordinary pipeline, and the owner's device merge (sann_merge_shards)."""
 
     def __init__(self, pkg, cluster_ids, list_offsets, tweet_ids, scores, n_shards: int, *, device: int = 0, n_partitions: int = 0):
         self.pkg, self.n_shards, self.device, self.n_partitions = pkg, n_shards, device, n_partitions
         cluster_ids = np.asarray(cluster_ids, np.int32)
         list_offsets = np.asarray(list_offsets, np.int64)
         self.bounds = cluster_range_bounds(np.diff(list_offsets), n_shards)
-        self.range_first = [int(cluster_ids[self.bounds[g]]) if self.bounds[g] < len(cluster_ids) else 1 << 31 for g in range(n_shards)]
         self.shards = []
         for g in range(n_shards):
             lo, hi = int(self.bounds[g]), int(self.bounds[g + 1])
             o = list_offsets[lo:hi + 1] - list_offsets[lo]
-            self.shards.append(pkg.ClusterTweetIndex(cluster_ids[lo:hi], o, tweet_ids[list_offsets[lo]:list_offsets[hi]],
-                                                     scores[list_offsets[lo]:list_offsets[hi]], device=device,
-                                                     n_partitions=n_partitions))  # every tweet, some clusters
+            ix = pkg.ClusterTweetIndex(cluster_ids[lo:hi], o, tweet_ids[list_offsets[lo]:list_offsets[hi]],
+                                       scores[list_offsets[lo]:list_offsets[hi]], device=device, n_partitions=n_partitions)  # every tweet, some clusters
+            self.shards.append(RangeShard(pkg, ix, g, n_shards, device=device, n_partitions=n_partitions))
         self.cluster_ids = cluster_ids
 
     def close(self):
         for s in self.shards:
-            s.close()
+            s.free()
+            s.index.close()
 
     def get_tweet_candidates(self, offs, cids, scs, cfg, *, now_ms: int, variant=None):
         """One batch, every query under `cfg`.  Returns (ids [nq, k], scores, counts, map_sizes, stats)."""
+        import ctypes as C
         pkg, N = self.pkg, self.n_shards
+        lib = pkg.load_library()
         nq, k = len(offs) - 1, min(int(cfg.maxNumResults), 1000)
         need = scanned_clusters(offs, cids, scs, int(cfg.maxScanClusters))
         M = max(int(cfg.maxTopTweetsPerCluster), 0)
-        # ---- every shard: the top-M prefix of each scanned list it owns ------------------------------------------------
-        l_c, l_t, l_s, l_src = [], [], [], []
-        for g, ix in enumerate(self.shards):
-            lo, hi = int(self.bounds[g]), int(self.bounds[g + 1])
-            mine = need[np.isin(need, self.cluster_ids[lo:hi])]
-            for c in mine:
-                t, s, _r = ix.get_list(int(c))
-                l_c.append(int(c)); l_t.append(t[:M]); l_s.append(s[:M]); l_src.append(g)
-        order = np.argsort(np.array(l_c, np.int64), kind="stable")  # the regrouped lists, by ascending cluster id
-        lens = np.array([len(l_t[i]) for i in order], np.int64)
-        g_off = np.concatenate([[0], np.cumsum(lens)])
-        g_c = np.array([l_c[i] for i in order], np.int32)
-        g_t = np.concatenate([l_t[i] for i in order]) if len(order) else np.empty(0, np.int64)
-        g_s = np.concatenate([l_s[i] for i in order]) if len(order) else np.empty(0, np.float64)
-        src = np.repeat(np.array([l_src[i] for i in order], np.int64), lens)
-        # ---- the exchange: posting -> GPU hash(tweetId) % N (csrc/sann_device.h tweet_shard; checked against the library)
-        lib = pkg.load_library()
-        dst = ((_mix64(g_t.view(np.uint64)) >> np.uint64(40)) % np.uint64(N)).astype(np.int64) if N > 1 else np.zeros(len(g_t), np.int64)
-        for i in range(0, len(g_t), max(1, len(g_t) // 8)):
-            assert dst[i] == lib.sann_tweet_shard(int(g_t[i]), N)
-        moved = int((src != dst).sum()) * 16
-        # ---- every GPU: its tweets' postings as a temporary tweet-hash shard, the ordinary pipeline on it ---------------
+        # ---- every shard, on the device: counts[cluster][dest], then the packed prefixes -----------------------------------
+        counts = [sh.export_counts(need, M) for sh in self.shards]          # [source][cluster][dest]
+        sends = [sh.export(need, M, counts[g]) for g, sh in enumerate(self.shards)]
+        # ---- the exchange (what sann_exchange_postings_by_tweet_hash does between processes): destination r receives, source by
+        # source, the segment each source packed for it
         per = []
-        for r in range(N):
-            ix = pkg.ClusterTweetIndex(g_c, g_off, g_t, g_s, device=self.device, n_partitions=self.n_partitions, shard_id=r, n_shards=N)
+        moved = total = 0
+        for r, sh in enumerate(self.shards):
+            recv_counts = np.array([int(counts[g][:, r].sum()) for g in range(N)], np.int64)
+            d_recv = sh._alloc(int(recv_counts.sum()) * 16)
+            o = 0
+            for g in range(N):
+                src_off = int(sends[g][1][:r].sum())
+                assert lib.sann_device_copy(self.device, C.c_void_p(d_recv + o * 16), C.c_void_p(sends[g][0] + src_off * 16), int(recv_counts[g]) * 16) == 0
+                o += int(recv_counts[g])
+                total += int(recv_counts[g])
+                moved += int(recv_counts[g]) if g != r else 0
+            to_me = np.zeros(len(need), np.int64)
+            for g in range(N):
+                to_me += counts[g][:, r]
+            # ---- its tweets' postings as a temporary index, the ordinary pipeline on it -----------------------------------
+            ix = sh.build_received(need, to_me, d_recv)
             qb = pkg.QueryBatch(ix, offs, cids, scs, cfg, now_ms=now_ms) if variant is None else \
                 pkg.QueryBatch(ix, offs, cids, scs, cfg, now_ms=now_ms, variant=variant)
             qb.run(); qb.finish()
-            per.append(qb.results())
+            per.append((qb, ix))
+        # ---- owner merge on the device: exact top-k of the N per-shard lists (sann_merge_shards; here every query has one owner)
+        stride = per[0][0].stride
+        arr = nq * stride * 8
+        buf = self.shards[0]._alloc(N * (2 * arr + 8 * nq))
+        for r, (qb, _ix) in enumerate(per):
+            (d_ids, d_sc, d_cnt, d_msz), _ = qb.device_results()
+            base = buf + r * (2 * arr + 8 * nq)
+            for dst, src, n in ((base, d_ids, arr), (base + arr, d_sc, arr), (base + 2 * arr, d_cnt, 4 * nq), (base + 2 * arr + 4 * nq, d_msz, 4 * nq)):
+                assert lib.sann_device_copy(self.device, C.c_void_p(dst), C.c_void_p(src), n) == 0
+        out = self.shards[0]._alloc(2 * arr + 8 * nq)
+        rc = lib.sann_merge_shards(self.device, None, N, nq, stride, 2 * arr + 8 * nq, C.c_void_p(buf), C.c_void_p(buf + arr), C.c_void_p(buf + 2 * arr),
+                                   C.c_void_p(buf + 2 * arr + 4 * nq), C.c_void_p(per[0][0].device_k()), C.c_void_p(out), C.c_void_p(out + arr),
+                                   C.c_void_p(out + 2 * arr), C.c_void_p(out + 2 * arr + 4 * nq))
+        assert rc == 0, lib.sann_last_error()
+        assert lib.sann_device_synchronize(self.device) == 0
+        ids = np.zeros((nq, stride), np.int64); sc = np.zeros((nq, stride)); cnt = np.zeros(nq, np.int32); msz = np.zeros(nq, np.int32)
+        for dst, src in ((ids, out), (sc, out + arr), (cnt, out + 2 * arr), (msz, out + 2 * arr + 4 * nq)):
+            assert lib.sann_device_copy(self.device, dst.ctypes.data_as(C.c_void_p), C.c_void_p(src), dst.nbytes) == 0
+        for qb, ix in per:
             qb.close(); ix.close()
-        # ---- owner merge: exact top-k of the N per-shard lists, (score desc by Double.compare, tweet id asc) -------------
-        ids = np.zeros((nq, k), np.int64); sc = np.zeros((nq, k)); cnt = np.zeros(nq, np.int32); msz = np.zeros(nq, np.int32)
-        for q in range(nq):
-            ti = np.concatenate([p[0][q, :p[2][q]] for p in per])
-            ts = np.concatenate([p[1][q, :p[2][q]] for p in per])
-            o = np.lexsort((ti, ~score_key(ts)))[:k]
-            cnt[q] = len(o); ids[q, :len(o)] = ti[o]; sc[q, :len(o)] = ts[o]
-            msz[q] = sum(int(p[3][q]) for p in per)
-        return ids, sc, cnt, msz, {"scanned_clusters": int(len(need)), "postings_regrouped": int(len(g_t)), "bytes_moved": moved,
-                                  "bytes_moved_per_gpu": moved // max(N, 1)}
+        for sh in self.shards:
+            sh.free()
+        return ids[:, :k], sc[:, :k], cnt, msz, {"scanned_clusters": int(len(need)), "postings_regrouped": total, "bytes_moved": moved * 16,
+                                                 "bytes_moved_per_gpu": moved * 16 // max(N, 1)}

@@ -197,6 +197,13 @@ _PROTOS = {
     "sann_batcher_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sann_heavy_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sann_index_export_prefix_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sann_index_export_prefixes_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sann_exchange_postings_by_tweet_hash": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sann_index_build_from_device_postings": (C.c_int, [C.POINTER(sann_index_options_t), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "sann_device_alloc": (C.c_int, [C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
+    "sann_device_free": (C.c_int, [C.c_int32, C.c_void_p]),
+    "sann_device_copy": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     "sann_debug_call_trace": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "sann_debug_normalise": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
     "sann_debug_wave_sort": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p]),
