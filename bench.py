@@ -45,6 +45,85 @@ def traffic_bytes(args, nq, world):
         return None
 
 
+def run_cluster_range(args, pkg, lib, index, comm, dist, torch, rank, world, local_rank, nq, nql, qsets, cfg, K, shard_k, now_ms, json_fd, t_corpus):
+    """--sharding cluster-range: rank g serves the clusters of id range g (equal id counts: at 100M tweets nearly every list is at
+    the index cap, so id count = posting mass); every step runs sharding.ClusterRangeRank.step -- export, exchange of the scanned
+    prefixes by tweet hash over RCCL, temporary index, ordinary batch, exchange to the owners, proving merge.  The batch's scanned
+    clusters (host arithmetic over the queries) are worked out before the timed region, like the prepared batches of the
+    tweet-hash path."""
+    import dataclasses
+    assert comm is not None, "--sharding cluster-range needs the library's RCCL communicator (backend nccl)"
+    sh = pkg.sharding
+    C_all = pkg.corpus.N_CLUSTERS
+    first = 1 + rank * C_all // world
+    end = 1 + (rank + 1) * C_all // world if rank + 1 < world else C_all + 1
+    rr = sh.ClusterRangeRank(pkg, index, comm, rank, world, first, end, device=local_rank, n_partitions=args.partitions)
+    cfg_run = cfg if shard_k == K else dataclasses.replace(cfg, maxNumResults=shard_k)
+    needs = [sh.scanned_clusters(o, c, s, int(cfg.maxScanClusters)) for (o, c, s) in qsets]
+    out_ids = torch.zeros((nql, K), dtype=torch.int64, device="cuda")
+    out_sc = torch.zeros((nql, K), dtype=torch.float64, device="cuda")
+    out_cnt = torch.zeros(nql, dtype=torch.int32, device="cuda")
+    out_msz = torch.zeros(nql, dtype=torch.int32, device="cuda")
+    d_bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = (out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), out_msz.data_ptr())
+    torch.cuda.synchronize()
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    info = None
+    for i in range(args.warmup):
+        info = rr.step(needs[i % len(needs)], qsets[i % len(qsets)], cfg_run, nql, K, shard_k, now_ms, out, d_bad.data_ptr())
+    sync()
+    t0 = time.perf_counter()
+    cand = sent = recvd = scanned = 0
+    for i in range(args.steps):
+        info = rr.step(needs[i % len(needs)], qsets[i % len(qsets)], cfg_run, nql, K, shard_k, now_ms, out, d_bad.data_ptr())
+        cand += int(out_cnt.sum().item())
+        sent += info["postings_sent"]; recvd += info["postings_received"]; scanned += info["postings_scanned"]
+    sync()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    tc = torch.tensor([cand, int(d_bad.item()), sent, scanned], dtype=torch.int64, device="cuda")
+    dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+    elapsed = float(tt.item())
+    # the last batch against the unsharded index (rank 0's own queries)
+    same = None
+    if rank == 0:
+        o, c, s = qsets[(args.steps - 1) % len(qsets)]
+        qf = pkg.QueryBatch(index, o[:nql + 1], c[:o[nql]], s[:o[nql]], cfg, now_ms=now_ms)
+        qf.run(); qf.finish()
+        f_ids, f_sc, f_cnt, f_msz = qf.results()
+        qf.close()
+        ids, scores, counts, msz = out_ids.cpu().numpy(), out_sc.cpu().numpy(), out_cnt.cpu().numpy(), out_msz.cpu().numpy()
+        same = bool(np.array_equal(f_cnt, counts) and np.array_equal(f_msz, msz) and np.array_equal(f_ids, ids) and
+                    np.array_equal(f_sc.view(np.int64), scores.view(np.int64)))
+    rr.close()
+    if rank == 0:
+        line = {
+            "metric": "candidates/sec + recall@400, 100M-tweet SimClusters-ANN @1/2/4/8 GPU", "value": int(tc[0].item()) / elapsed,
+            "unit": "candidates/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"batched simclusters-ann, {nq} concurrent user queries, {args.tweets} tweets x 144428 clusters, top-400, N=50 M=800 "
+                                   f"{args.alg}, {world}xMI355X cluster-id-range shards: scanned prefixes exchanged by tweet hash over RCCL every batch, "
+                                   f"temporary index, owners' proving merge",
+                       "queries": nq, "tweets": args.tweets, "clusters": 144428, "k": 400, "sharding": "cluster-range", "shard_list_length": shard_k,
+                       "queries_not_proven_by_cut_lists": int(tc[1].item()), "rotated_query_batches": len(qsets)},
+            "queries_per_sec": nq * args.steps / elapsed, "postings_per_sec": int(tc[3].item()) / elapsed,
+            "exchange_postings_per_step_all_gpus": int(tc[2].item()) / max(args.steps, 1),
+            "exchange_bytes_per_gpu_per_step": int(tc[2].item()) * 16 / max(args.steps, 1) / world,
+            "sharded_equals_unsharded": same, "fallback_units": info["fallback_units"] if info else 0,
+            "roofline": None, "cpu_baseline": None, "corpus_build_s": t_corpus,
+        }
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    dist.barrier()
+    lib.sann_comm_destroy(comm)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="sann", choices=["sann", "dense", "hnsw"],
@@ -70,6 +149,10 @@ def main():
                          "rehearse the N > 1 code path with several ranks sharing one GPU")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="N = 1 only: run the sharded path (process group, all-to-all, owner merge) with one shard")
+    ap.add_argument("--sharding", default="tweet-hash", choices=["tweet-hash", "cluster-range"],
+                    help="N > 1 (or --exercise-exchange): tweet-hash shards (the deployment: no data moves before the top-k) or the "
+                         "cluster-id-range shards north_star names (every batch moves the scanned lists' top-M prefixes to the GPU "
+                         "their tweets hash to: exact, and 17x the exchange bytes -- DESIGN.md section 4)")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight: consecutive steps alternate between this many HIP streams")
     ap.add_argument("--rotate", type=int, default=8,
                     help="distinct prepared query batches the timed loop rotates through (each its own 1024*N synthetic users): 8 "
@@ -149,6 +232,8 @@ def main():
     t0 = time.time()
     nq = args.queries_per_gpu * world
     nql = args.queries_per_gpu  # queries this rank owns (finalises); it still answers all nq on its shard
+    range_mode = args.sharding == "cluster-range" and (world > 1 or args.exercise_exchange)
+    p_full = args.partitions
     if world > 1:
         # a shard holds 1/world of every posting list: keep the (query, partition) units about the same size by
         # partitioning the shard world times less finely, down to 4 partitions (measured with tools/shard_cost.py on the
@@ -168,9 +253,11 @@ def main():
             qsets.append((o_all[i * nq:(i + 1) * nq + 1] - lo, c_all[lo:hi], s_all[lo:hi]))
     now_ms = pkg.corpus.NOW_MS
     if args.corpus == "device":
+        # cluster-range ranks each generate the whole corpus (the generator has no range filter) and serve only their range
         index = pkg.ClusterTweetIndex.synthetic(args.tweets, pkg.corpus.N_CLUSTERS, seed=pkg.corpus.CORPUS_SEED,
                                                 index_cap=2000, now_ms=now_ms, device=local_rank,
-                                                n_partitions=args.partitions, shard_id=rank, n_shards=world)
+                                                n_partitions=p_full if range_mode else args.partitions, shard_id=0 if range_mode else rank,
+                                                n_shards=1 if range_mode else world)
         co = None
     else:
         co = pkg.corpus.make_corpus(args.tweets)
@@ -228,6 +315,9 @@ def main():
         comm = ctypes.c_void_p()
         rc = lib.sann_comm_create(local_rank, rank, world, uid[0], ctypes.byref(comm))
         assert rc == 0, lib.sann_last_error()
+    if args.sharding == "cluster-range" and sharded:
+        return run_cluster_range(args, pkg, lib, index, comm, dist, torch, rank, world, local_rank, nq, nql, qsets[:n_rot], cfg, K, shard_k,
+                                 now_ms, json_fd, t_corpus)
     inexact_seen = 0
     while True:
         cfg_run = cfg if shard_k == K else dataclasses.replace(cfg, maxNumResults=shard_k)

@@ -84,6 +84,129 @@ def test_two_rank_gloo_shard_merge_is_exact():
     assert out.get(0) is True and out.get(1) is True
 
 
+def _range_worker(rank, world, port, out):
+    """The cluster-id-range deployment's message flow between two gloo ranks: rank g holds WHOLE lists of the clusters of its id
+    range; per batch it counts the scanned prefixes by destination (sann_tweet_shard), the counts cross, the (id, score) records
+    cross packed destination-major exactly as sann_index_export_prefixes_device lays them out (clusters ascending inside a
+    destination, ranks ascending inside a cluster), the receiver turns source-major arrival order into its temporary CSR (which
+    is what sharding.RangeShard.build_received hands the library), the oracle answers the batch on it, and the owners merge."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    from _pkg import load_package
+    import oracle
+
+    pkg = load_package()
+    lib = pkg.load_library()
+    sh_ = pkg.sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def all_to_all_bytes(blocks):
+        """blocks[r] = bytes for rank r (any lengths): what arrives, by source.  gloo: all-gather of everything, then slice."""
+        lens = torch.tensor([len(b) for b in blocks], dtype=torch.int64)
+        all_lens = [torch.zeros_like(lens) for _ in range(world)]
+        dist.all_gather(all_lens, lens)
+        width = int(max(int(l.sum()) for l in all_lens))
+        mine = torch.zeros(max(width, 1), dtype=torch.uint8)
+        flat = np.concatenate([np.frombuffer(b, np.uint8) for b in blocks]) if width else np.zeros(0, np.uint8)
+        mine[:len(flat)] = torch.from_numpy(flat.copy())
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        got = []
+        for s in range(world):
+            o = int(all_lens[s][:rank].sum())
+            got.append(parts[s][o:o + int(all_lens[s][rank])].numpy().tobytes())
+        return got
+
+    try:
+        co = pkg.corpus.make_corpus(20000, 800, seed=5, index_cap=300)
+        nq, k, M = 12, 120, 200
+        nql = nq // world
+        offs, cids, scs = pkg.corpus.make_queries(nq, 800, seed=6, clusters_per_user=30)
+        cfg = pkg.SimClustersANNConfig(maxNumResults=k, maxTopTweetsPerCluster=M, maxScanClusters=30)
+        shard_k = sh_.shard_list_length(k, world)
+        cfg_shard = dataclasses.replace(cfg, maxNumResults=shard_k)
+        bounds = sh_.cluster_range_bounds(np.diff(co.list_offsets), world)  # list positions [bounds[g], bounds[g+1]) are rank g's
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        my_clusters = co.cluster_ids[lo:hi]
+        need = sh_.scanned_clusters(offs, cids, scs, cfg.maxScanClusters)
+        mine = np.isin(need, my_clusters)
+        # 1. counts[cluster][dest] of my range's scanned prefixes, and the records, destination-major
+        counts = np.zeros((len(need), world), np.int32)
+        rec = [[] for _ in range(world)]
+        rec_t = np.dtype([("id", "<i8"), ("score", "<f8")])
+        for ci in np.nonzero(mine)[0]:
+            li = int(np.searchsorted(co.cluster_ids, need[ci]))
+            b, e = co.list_offsets[li], min(co.list_offsets[li + 1], co.list_offsets[li] + M)
+            dest = np.array([lib.sann_tweet_shard(int(x), world) for x in co.tweet_ids[b:e]], np.int64)
+            for d in range(world):
+                sel = dest == d
+                counts[ci, d] = int(sel.sum())
+                r = np.zeros(int(sel.sum()), rec_t)
+                r["id"], r["score"] = co.tweet_ids[b:e][sel], co.scores[b:e][sel]
+                rec[d].append(r)
+        # 2. the counts cross (block r of my message = counts[:, r]) ...
+        got_counts = all_to_all_bytes([np.ascontiguousarray(counts[:, d]).tobytes() for d in range(world)])
+        from_src = np.stack([np.frombuffer(g, np.int32) for g in got_counts]).astype(np.int64)  # [source][cluster]
+        assert ((from_src > 0).sum(axis=0) <= 1).all()  # a cluster has ONE source
+        # 3. ... then the postings
+        got = all_to_all_bytes([(np.concatenate(r) if r else np.zeros(0, rec_t)).tobytes() for r in rec])
+        for s in range(world):
+            assert len(got[s]) == 16 * int(from_src[s].sum())
+        arrived = np.concatenate([np.frombuffer(g, rec_t) for g in got])
+        # 4. source-major arrival order IS ascending cluster order (ranges ascend with the rank): the temporary CSR
+        to_me = from_src.sum(axis=0)
+        keep = to_me > 0
+        t_cl = need[keep]
+        t_off = np.concatenate([[0], np.cumsum(to_me[keep])]).astype(np.int64)
+        assert t_off[-1] == len(arrived)
+        for i, c in enumerate(t_cl):  # every list: my tweets of the global top-M prefix, in rank order
+            li = int(np.searchsorted(co.cluster_ids, c))
+            b, e = co.list_offsets[li], min(co.list_offsets[li + 1], co.list_offsets[li] + M)
+            want = [int(x) for x in co.tweet_ids[b:e] if lib.sann_tweet_shard(int(x), world) == rank]
+            assert arrived["id"][t_off[i]:t_off[i + 1]].tolist() == want
+        sh = (t_cl, t_off, arrived["id"].copy(), arrived["score"].copy())
+        # 5. the ordinary batch on the temporary index, then the owners' exchange and proving merge (as the tweet-hash test)
+        ids = np.zeros((nq, shard_k), np.int64); sc = np.zeros((nq, shard_k)); cnt = np.zeros(nq, np.int32); msz = np.zeros(nq, np.int32)
+        for q in range(nq):
+            i, s, m = oracle.sann_query(cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]], None, cfg_shard, co.now_ms, *sh)
+            ids[q, :len(i)] = i; sc[q, :len(i)] = s; cnt[q] = len(i); msz[q] = m
+        send = torch.from_numpy(sh_.pack_for_owners(ids, sc, cnt, msz, world))
+        parts = [torch.zeros_like(send) for _ in range(world)]
+        dist.all_gather(parts, send)
+        size = send.numel() // world
+        recv = torch.cat([p[rank * size:(rank + 1) * size] for p in parts]).numpy()
+        g_ids, g_sc, g_cnt, g_msz = sh_.unpack_from_shards(recv, world, nql, shard_k)
+        ok = True
+        for ql in range(nql):
+            q = rank * nql + ql
+            m_ids, m_sc, proven = sh_.merge_cut_lists(g_ids[:, ql], g_sc[:, ql], g_cnt[:, ql], k, shard_k)
+            o_i, o_s, o_m = oracle.sann_query(cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]], None, cfg, co.now_ms,
+                                              co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores)
+            ok &= proven and m_ids.tolist() == o_i.tolist() and m_sc.tolist() == o_s.tolist() and int(g_msz[:, ql].sum()) == o_m
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_cluster_range_exchange_is_exact():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = 31700 + os.getpid() % 2000
+    procs = [ctx.Process(target=_range_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert out.get(0) is True and out.get(1) is True
+
+
 def test_shard_and_partition_hash_are_stable(pkg):
     lib = pkg.load_library()
     ids = [0, 1, -1, 2**40 + 12345, 1724188722590646272]

@@ -296,3 +296,112 @@ class ClusterRangeDeployment:
             sh.free()
         return ids[:, :k], sc[:, :k], cnt, msz, {"scanned_clusters": int(len(need)), "postings_regrouped": total, "bytes_moved": moved * 16,
                                                  "bytes_moved_per_gpu": moved * 16 // max(N, 1)}
+
+
+class ClusterRangeRank:
+    """ONE rank of the cluster-id-range deployment with one process per GPU (bench.py --sharding cluster-range): every step
+    through the library -- export counts, counts to the destinations (sann_exchange_to_owners), packed prefixes
+    (sann_index_export_prefixes_device), postings to the GPU their tweet hashes to (sann_exchange_postings_by_tweet_hash over
+    RCCL), a temporary index of this GPU's tweets (sann_index_build_from_device_postings), the ordinary batch on it with its
+    results bound owner-chunked, results to the owners (sann_exchange_to_owners) and the owner's proving merge
+    (sann_merge_shards_cut).  `index` may hold more clusters than the rank's range [first_cluster, end_cluster): only the
+    range is ever exported (the synthetic generator has no range filter, so every rank of the bench generates the corpus)."""
+
+    def __init__(self, pkg, index, comm, rank: int, world: int, first_cluster: int, end_cluster: int, *, device: int, n_partitions: int):
+        import ctypes as C
+        self.C = C
+        self.pkg, self.comm, self.rank, self.world, self.device = pkg, comm, rank, world, device
+        self.lib = pkg.load_library()
+        self.shard = RangeShard(pkg, index, rank, world, device=device, n_partitions=n_partitions)
+        self.first, self.end = first_cluster, end_cluster
+        self._grow = {}
+
+    def _buf(self, name: str, n_bytes: int) -> int:
+        """A named device buffer that only grows."""
+        cur = self._grow.get(name)
+        if cur is None or cur[1] < n_bytes:
+            if cur is not None:
+                self.lib.sann_device_free(self.device, cur[0])
+            p = self.C.c_void_p()
+            want = int(n_bytes * 1.25) + 4096
+            assert self.lib.sann_device_alloc(self.device, want, self.C.byref(p)) == 0, self.lib.sann_last_error()
+            cur = (p.value, want)
+            self._grow[name] = cur
+        return cur[0]
+
+    def close(self):
+        for p, _ in self._grow.values():
+            self.lib.sann_device_free(self.device, p)
+        self._grow = {}
+        self.shard.free()
+
+    def step(self, need: np.ndarray, queries, cfg_run, nql: int, K: int, shard_k: int, now_ms: int, out, d_bad: int, stream: int = 0):
+        """One batch.  need = the batch's scanned clusters (ascending); queries = (offs, cids, scs) of ALL world * nql queries;
+        out = device pointers (ids, scores, counts, map sizes) of this rank's nql merged results."""
+        C, lib, N, me = self.C, self.lib, self.world, self.rank
+        M = max(int(cfg_run.maxTopTweetsPerCluster), 0)
+        st = C.c_void_p(stream)
+        # 1. counts[cluster][dest] of the clusters of MY range
+        mine = (need >= self.first) & (need < self.end)
+        counts = np.zeros((len(need), N), np.int32)
+        if mine.any():
+            counts[mine] = self.shard.export_counts(need[mine], M)
+        # 2. every destination learns what each source will send it: block r of my message = counts[:, r]
+        blk = (len(need) * 4 + 7) // 8 * 8
+        d_cs, d_cr = self._buf("cs", N * blk), self._buf("cr", N * blk)
+        h = np.zeros((N, blk // 4), np.int32)
+        h[:, :len(need)] = counts.T
+        assert lib.sann_device_copy(self.device, C.c_void_p(d_cs), h.ctypes.data_as(C.c_void_p), h.nbytes) == 0
+        assert lib.sann_exchange_to_owners(self.comm, st, C.c_void_p(d_cs), C.c_void_p(d_cr), blk) == 0, lib.sann_last_error()
+        assert lib.sann_device_synchronize(self.device) == 0
+        got = np.zeros((N, blk // 4), np.int32)
+        assert lib.sann_device_copy(self.device, got.ctypes.data_as(C.c_void_p), C.c_void_p(d_cr), got.nbytes) == 0
+        from_src = got[:, :len(need)].astype(np.int64)  # [source][cluster] postings for me
+        # 3. the packed prefixes, destination-major
+        per_dest = counts.sum(axis=0).astype(np.int64)
+        d_send = self._buf("send", int(per_dest.sum()) * 16)
+        if mine.any():
+            own = counts[mine]
+            dest_base = np.concatenate([[0], np.cumsum(per_dest)])
+            seg = np.ascontiguousarray(dest_base[:-1][None, :] + np.concatenate([np.zeros((1, N), np.int64), np.cumsum(own, axis=0)[:-1]]), np.int64)
+            cl = np.ascontiguousarray(need[mine], np.int32)
+            assert lib.sann_index_export_prefixes_device(self.shard.index.handle, st, len(cl), cl.ctypes.data_as(C.c_void_p), M, N,
+                                                         seg.ctypes.data_as(C.c_void_p), C.c_void_p(d_send)) == 0, lib.sann_last_error()
+        # 4. postings to the GPU their tweet hashes to
+        recv_counts = np.ascontiguousarray(from_src.sum(axis=1), np.int64)
+        d_recv = self._buf("recv", int(recv_counts.sum()) * 16)
+        sc_ = np.ascontiguousarray(per_dest, np.int64)
+        assert lib.sann_exchange_postings_by_tweet_hash(self.comm, st, C.c_void_p(d_send), sc_.ctypes.data_as(C.c_void_p), C.c_void_p(d_recv),
+                                                        recv_counts.ctypes.data_as(C.c_void_p)) == 0, lib.sann_last_error()
+        assert lib.sann_device_synchronize(self.device) == 0
+        # 5. my tweets' postings as a temporary index (sources' ranges ascend with the rank: arrival order = ascending clusters)
+        ix = self.shard.build_received(need, from_src.sum(axis=0), d_recv)
+        # 6. the ordinary batch on it, results bound owner-chunked
+        offs, cids, scs = queries
+        qb = self.pkg.QueryBatch(ix, offs, cids, scs, cfg_run, now_ms=now_ms)
+        stride = qb.stride
+        chunk, _ = owner_message_layout(nql, stride)
+        arr = nql * stride * 8
+        d_msg, d_got = self._buf("msg", N * chunk), self._buf("got", N * chunk)
+        qb.bind_outputs_chunked(d_msg, d_msg + arr, d_msg + 2 * arr, d_msg + 2 * arr + 4 * nql, nql, chunk)
+        qb.run(stream)
+        qb.finish(stream)
+        unit_ms = 0.0
+        # 7. results to the owners, proving merge
+        assert lib.sann_exchange_to_owners(self.comm, st, C.c_void_p(d_msg), C.c_void_p(d_got), chunk) == 0, lib.sann_last_error()
+        o_ids, o_sc, o_cnt, o_msz = out
+        if shard_k < K:
+            rc = lib.sann_merge_shards_cut(self.device, st, N, nql, stride, chunk, shard_k, K, K, C.c_void_p(d_got), C.c_void_p(d_got + arr),
+                                           C.c_void_p(d_got + 2 * arr), C.c_void_p(d_got + 2 * arr + 4 * nql), C.c_void_p(o_ids), C.c_void_p(o_sc),
+                                           C.c_void_p(o_cnt), C.c_void_p(o_msz), C.c_void_p(d_bad))
+        else:
+            rc = lib.sann_merge_shards(self.device, st, N, nql, stride, chunk, C.c_void_p(d_got), C.c_void_p(d_got + arr), C.c_void_p(d_got + 2 * arr),
+                                       C.c_void_p(d_got + 2 * arr + 4 * nql), C.c_void_p(qb.device_k() + self.rank * nql * 4), C.c_void_p(o_ids),
+                                       C.c_void_p(o_sc), C.c_void_p(o_cnt), C.c_void_p(o_msz))
+        assert rc == 0, lib.sann_last_error()
+        assert lib.sann_device_synchronize(self.device) == 0
+        stats = qb.stats()
+        qb.close()
+        ix.close()
+        return {"postings_sent": int(per_dest.sum() - per_dest[me]), "postings_received": int(recv_counts.sum() - recv_counts[me]),
+                "postings_scanned": int(stats.postings_scanned), "fallback_units": int(stats.n_fallback_units), "unit_ms": unit_ms}
