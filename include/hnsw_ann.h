@@ -71,16 +71,30 @@ int hnsw_index_build_insert(int32_t device, int32_t metric, int64_t n, int32_t d
 int hnsw_index_build_insert_levels(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors,
                                    const int64_t *ids, int32_t max_m, int32_t ef_construction, const int32_t *levels,
                                    int32_t n_threads, hnsw_index_t **out);
-/* Build on the device: the items of the upper layers are inserted on the host as above (they fix the entry point and every
- * layer above 0); all others -- which only ever touch layer 0 -- go in in batches on the GPU: a batch searches one
- * snapshot of the graph with beam ef_construction (the walk kernel), every item selects its neighbours by the
- * reference's heuristic, and the back links are applied per target node by one wave (append while the list has room,
- * else re-select by the heuristic, HnswIndex.java:414-427).  This is the reference's multi-writer mode taken wide: items
- * of one batch do not see each other, so the graph is not the sequential one ("when using concurrent writers we can miss
- * connections", :376-380); its quality is what recall against the exhaustive search says.  ef_construction <= 256;
- * batch = items per round (0 = 4096). */
+/* Build on the device, every step of it, and deterministically: two builds of one input give one graph.  The reference's
+ * multi-writer insertion (HnswIndex.java:150-200; "when using concurrent writers we can miss connections", :376-380) with the
+ * interleaving fixed:
+ *   order   items by (level descending, position ascending); the first is the entry point and carries maxLevel
+ *   rounds  the next min(batch, max(1, linked / 8)) items of the order are inserted against ONE snapshot of the graph
+ *   A       per item, wireConnectionForAllLayers (:137-148): bestEntryPointUntilLayer, then per layer
+ *           searchLayerForCandidates(efConstruction), selectNearestNeighboursByHeuristic(maxM), the item's own list,
+ *           neighbours.get(0) as the next layer's entry; back links are recorded as (layer, neighbour, order index)
+ *   B       per (layer, node), all its additions of the round in order-index order: appended while the list has room
+ *           (:414-417), else one re-selection by the heuristic over old list ++ additions sorted ascending by
+ *           (Float.compare distance, position) (:419-427 does that per addition)
+ * Bounds the reference does not have, counted in hnsw_index_build_stats: a walk's candidate queue holds 1024 entries (when
+ * full, entries beyond the current bound -- never expanded, :589-591 -- are dropped and the heap rebuilt in array order); a
+ * re-selection sees the first 1024 of old list ++ additions.  oracle/hnsw_oracle.c restates exactly this
+ * (oracle_hnsw_build_batched); tests/test_hnsw_gpu_build_gpu.py compares the graphs entry for entry.
+ * ef_construction <= 256; batch = items per round (0 = 4096).  _levels: every item's level given (0..60) instead of drawn. */
 int hnsw_index_build_insert_gpu(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
                                 int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t batch, hnsw_index_t **out);
+int hnsw_index_build_insert_gpu_levels(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                                       int32_t max_m, int32_t ef_construction, const int32_t *levels, int32_t batch, hnsw_index_t **out);
+/* Counters of the last device build of this index (any pointer may be NULL): rounds run, additions a re-selection did not see,
+ * candidate-queue prunes, candidates dropped because a pruned queue was still full. */
+int hnsw_index_build_stats(const hnsw_index_t *index, int64_t *rounds, int64_t *unseen_additions, int64_t *queue_prunes,
+                           int64_t *dropped_candidates);
 int hnsw_index_graph_size(const hnsw_index_t *index, int64_t *n_entries, int64_t *n_neighbours, int64_t *entry_point,
                           int32_t *max_level);
 int hnsw_index_graph(const hnsw_index_t *index, int32_t *entry_level, int64_t *entry_item, int64_t *entry_offsets,

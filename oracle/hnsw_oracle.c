@@ -367,3 +367,209 @@ int64_t oracle_hnsw_build(int32_t metric, int64_t n, int32_t d, const float *x, 
   free(g.cnt); free(g.nb); free(visited);
   return fits ? ne : -1;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The device builder's batched insertion, restated on the CPU (include/hnsw_ann.h, hnsw_index_build_insert_gpu): the
+ * reference's multi-writer mode (HnswIndex.java:150-200,376-380) with the interleaving fixed.
+ *   order   items by (level descending, position ascending); order[0] is the entry point, maxLevel = its level
+ *   rounds  the next min(batch, max(1, linked / 8)) items are wired against one snapshot of the graph
+ *   A       wireConnectionForAllLayers (:137-148) per item with the functions above, except that the item's back links are
+ *           only recorded; the walk's candidate queue holds ccap entries -- when full, entries beyond the current bound
+ *           (never expanded, :589-591) are dropped and the heap is rebuilt by re-offering the survivors in array order
+ *   B       per (layer, node), additions in order-index order: appended while there is room (:414-417), else ONE
+ *           re-selection by the heuristic (:495-523) over the first link_cap of old list ++ additions, ascending by
+ *           (Float.compare distance, position)
+ * ------------------------------------------------------------------------------------------------------------------ */
+static int64_t g_batched_prunes = 0; /* of the last oracle_hnsw_build_batched */
+int64_t oracle_hnsw_batched_prunes(void) { return g_batched_prunes; }
+static void search_layer_bounded(const hbuild *g, int64_t item, int64_t entry, int ef, int level, uint8_t *visited, jpq *wq, int ccap) {
+  jpq cq;
+  jpq_init(&cq, 1);
+  jpq_init(wq, 0);
+  qitem first = {item_distance(g, item, entry), entry};
+  jpq_offer(&cq, first);
+  jpq_offer(wq, first);
+  memset(visited, 0, (size_t)g->n);
+  visited[entry] = 1;
+  float lower = wq->a[0].d;
+  while (cq.n > 0) {
+    qitem cand = cq.a[0];
+    if (cand.d > lower) break;
+    jpq_poll(&cq);
+    const int64_t *list;
+    int ln = list_of(g, level, cand.item, &list);
+    for (int j = 0; j < ln; j++) {
+      int64_t nn = list[j];
+      if (visited[nn]) continue;
+      visited[nn] = 1;
+      float dist = item_distance(g, item, nn);
+      if (wq->n < ef || dist < wq->a[0].d) {
+        qitem it = {dist, nn};
+        if (cq.n >= ccap) { /* prune */
+          g_batched_prunes++;
+          int had = cq.n;
+          qitem *old = malloc(sizeof(qitem) * (size_t)had);
+          memcpy(old, cq.a, sizeof(qitem) * (size_t)had);
+          cq.n = 0;
+          for (int s = 0; s < had; s++) if (!(old[s].d > lower)) jpq_offer(&cq, old[s]);
+          free(old);
+        }
+        if (cq.n < ccap) jpq_offer(&cq, it);
+        jpq_offer(wq, it);
+        if (wq->n > ef) jpq_poll(wq);
+        lower = wq->a[0].d;
+      }
+    }
+  }
+  free(cq.a);
+}
+
+typedef struct { int level; int64_t target; int64_t t; } backlink;
+static int backlink_cmp(const void *pa, const void *pb) {
+  const backlink *a = pa, *b = pb;
+  if (a->level != b->level) return a->level < b->level ? -1 : 1;
+  if (a->target != b->target) return a->target < b->target ? -1 : 1;
+  return a->t < b->t ? -1 : (a->t > b->t ? 1 : 0);
+}
+
+int64_t oracle_hnsw_build_batched(int32_t metric, int64_t n, int32_t d, const float *x, const int32_t *levels, int32_t max_m,
+                                  int32_t ef_construction, int32_t batch, int32_t ccap, int32_t link_cap, int64_t cap_entries,
+                                  int64_t cap_neighbours, int32_t *entry_level, int64_t *entry_item, int64_t *entry_offsets,
+                                  int64_t *entry_neighbours, int64_t *entry_point, int32_t *max_level) {
+  hbuild g;
+  g_batched_prunes = 0;
+  g.n = n; g.metric = metric; g.d = d; g.max_m = max_m; g.max_m0 = 2 * max_m; g.efc = ef_construction; g.x = x;
+  g.cap = 2 * max_m + 1;
+  g.entry = -1; g.max_level = -1;
+  int top = 0;
+  for (int64_t i = 0; i < n; i++) if (levels[i] > top) top = levels[i];
+  g.n_levels = top + 1;
+  g.cnt = malloc(sizeof(int32_t *) * (size_t)g.n_levels);
+  g.nb = malloc(sizeof(int64_t *) * (size_t)g.n_levels);
+  for (int l = 0; l < g.n_levels; l++) {
+    g.cnt[l] = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; i++) g.cnt[l][i] = -1;
+    g.nb[l] = malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1) * (size_t)g.cap);
+  }
+  uint8_t *visited = malloc((size_t)(n > 0 ? n : 1));
+  /* order: level descending, position ascending (a counting sort by level) */
+  int64_t *order = malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+  {
+    int64_t at = 0;
+    for (int l = top; l >= 0; l--)
+      for (int64_t i = 0; i < n; i++) if (levels[i] == l) order[at++] = i;
+  }
+  if (n > 0) { g.entry = order[0]; g.max_level = levels[order[0]]; }
+  backlink *links = malloc(sizeof(backlink) * (size_t)(batch > 0 ? batch : 1) * (size_t)(top + 1) * (size_t)max_m);
+  int64_t *neigh = malloc(sizeof(int64_t) * (size_t)(g.cap + 1));
+  int64_t *tid = malloc(sizeof(int64_t) * (size_t)link_cap), *cid = malloc(sizeof(int64_t) * (size_t)link_cap);
+  float *td = malloc(sizeof(float) * (size_t)link_cap), *cd = malloc(sizeof(float) * (size_t)link_cap);
+  int64_t at = 1, linked = 1;
+  while (at < n) {
+    int64_t m = linked / 8;
+    if (m < 1) m = 1;
+    if (m > batch) m = batch;
+    if (m > n - at) m = n - at;
+    int64_t nl = 0;
+    /* ---- A: every item of the round against the snapshot (the new items' own lists are not reachable from it) ---- */
+    for (int64_t t = 0; t < m; t++) {
+      const int64_t item = order[at + t];
+      const int cur_level = levels[item];
+      int64_t cur = g.entry;
+      if (cur_level < g.max_level) {
+        float cur_dist = item_distance(&g, item, cur);
+        for (int level = g.max_level; level > cur_level; level--) {
+          int changed = 1;
+          while (changed) {
+            changed = 0;
+            const int64_t *list;
+            int ln = list_of(&g, level, cur, &list);
+            for (int j = 0; j < ln; j++) {
+              float dd = item_distance(&g, item, list[j]);
+              if (dd < cur_dist) { cur_dist = dd; cur = list[j]; changed = 1; }
+            }
+          }
+        }
+      }
+      for (int level = cur_level < g.max_level ? cur_level : g.max_level; level >= 0; level--) {
+        jpq wq;
+        search_layer_bounded(&g, item, cur, g.efc, level, visited, &wq, ccap);
+        int nn = select_by_heuristic(&g, &wq, item, g.max_m, neigh);
+        put_list(&g, level, item, neigh, nn);
+        for (int e = 0; e < nn; e++) { links[nl].level = level; links[nl].target = neigh[e]; links[nl].t = t; nl++; }
+        cur = neigh[0];
+        free(wq.a);
+      }
+    }
+    /* (the new items' lists must not be visible to the walks of the same round: they are not, since no old list points
+     * to a new item before B runs and the entry point is old) */
+    /* ---- B ---- */
+    qsort(links, (size_t)nl, sizeof(backlink), backlink_cmp);
+    for (int64_t i0 = 0; i0 < nl;) {
+      int64_t i1 = i0;
+      while (i1 < nl && links[i1].level == links[i0].level && links[i1].target == links[i0].target) i1++;
+      const int level = links[i0].level;
+      const int64_t base = links[i0].target;
+      const int M = level == 0 ? g.max_m0 : g.max_m;
+      const int64_t *conn;
+      int old_n = list_of(&g, level, base, &conn);
+      const int add_n = (int)(i1 - i0);
+      if (old_n + add_n <= M) {
+        int64_t *upd = malloc(sizeof(int64_t) * (size_t)(M + 1));
+        if (old_n > 0) memcpy(upd, conn, sizeof(int64_t) * (size_t)old_n);
+        for (int e = 0; e < add_n; e++) upd[old_n + e] = order[at + links[i0 + e].t];
+        put_list(&g, level, base, upd, old_n + add_n);
+        free(upd);
+      } else {
+        int cn = old_n + add_n;
+        if (cn > link_cap) cn = link_cap;
+        for (int i = 0; i < cn; i++) {
+          tid[i] = i < old_n ? conn[i] : order[at + links[i0 + (i - old_n)].t];
+          td[i] = item_distance(&g, base, tid[i]);
+        }
+        for (int i = 0; i < cn; i++) { /* ascending by (Float.compare, position) */
+          int rank = 0;
+          for (int e = 0; e < cn; e++) {
+            int c = jfloat_compare(td[e], td[i]);
+            rank += (c < 0 || (c == 0 && e < i)) ? 1 : 0;
+          }
+          cid[rank] = tid[i];
+          cd[rank] = td[i];
+        }
+        int64_t *upd = malloc(sizeof(int64_t) * (size_t)(M + 1));
+        int nk = 0;
+        for (int i = 0; i < cn && nk < M; i++) {
+          if (cid[i] == base) continue;
+          int include = 1;
+          for (int k = 0; k < nk; k++)
+            if (item_distance(&g, upd[k], cid[i]) < cd[i]) { include = 0; break; }
+          if (include) upd[nk++] = cid[i];
+        }
+        put_list(&g, level, base, upd, nk);
+        free(upd);
+      }
+      i0 = i1;
+    }
+    at += m;
+    linked += m;
+  }
+  int64_t ne = 0, nnb = 0;
+  int fits = 1;
+  for (int l = 0; l < g.n_levels && fits; l++)
+    for (int64_t i = 0; i < n; i++) {
+      if (g.cnt[l][i] < 0) continue;
+      if (ne >= cap_entries || nnb + g.cnt[l][i] > cap_neighbours) { fits = 0; break; }
+      entry_level[ne] = l;
+      entry_item[ne] = i;
+      entry_offsets[ne] = nnb;
+      memcpy(entry_neighbours + nnb, g.nb[l] + (size_t)i * g.cap, sizeof(int64_t) * (size_t)g.cnt[l][i]);
+      nnb += g.cnt[l][i];
+      ne++;
+    }
+  if (fits) entry_offsets[ne] = nnb;
+  *entry_point = g.entry;
+  *max_level = g.max_level;
+  for (int l = 0; l < g.n_levels; l++) { free(g.cnt[l]); free(g.nb[l]); }
+  free(g.cnt); free(g.nb); free(visited); free(order); free(links); free(neigh); free(tid); free(cid); free(td); free(cd);
+  return fits ? ne : -1;
+}

@@ -283,6 +283,28 @@ def hnsw_build(metric: int, stored: np.ndarray, levels, max_m: int, ef_construct
     return e_lv[:ne].copy(), e_it[:ne].copy(), e_off[:ne + 1].copy(), e_nb[:e_off[ne]].copy(), entry.value, ml.value
 
 
+def hnsw_build_batched(metric: int, stored: np.ndarray, levels, max_m: int, ef_construction: int, batch: int = 4096,
+                       ccap: int = 1024, link_cap: int = 1024):
+    """The device builder's batched insertion restated (oracle/hnsw_oracle.c, oracle_hnsw_build_batched): the graph
+    hnsw_index_build_insert_gpu[_levels] must produce, in the form hnsw_search takes."""
+    L = lib()
+    L.oracle_hnsw_build_batched.restype = C.c_int64
+    x = np.ascontiguousarray(stored, np.float32)
+    lv_in = np.ascontiguousarray(levels, np.int32)
+    n = x.shape[0]
+    cap_e = n * (int(lv_in.max(initial=0)) + 1) + 1
+    cap_n = cap_e * (2 * max_m + 1)
+    e_lv = np.zeros(cap_e, np.int32); e_it = np.zeros(cap_e, np.int64)
+    e_off = np.zeros(cap_e + 1, np.int64); e_nb = np.zeros(cap_n, np.int64)
+    entry = C.c_int64(); ml = C.c_int32()
+    ne = L.oracle_hnsw_build_batched(C.c_int32(metric), C.c_int64(n), C.c_int32(x.shape[1]), _p(x), _p(lv_in), C.c_int32(max_m),
+                                     C.c_int32(ef_construction), C.c_int32(batch), C.c_int32(ccap), C.c_int32(link_cap),
+                                     C.c_int64(cap_e), C.c_int64(cap_n), _p(e_lv), _p(e_it), _p(e_off), _p(e_nb), C.byref(entry),
+                                     C.byref(ml))
+    assert ne >= 0
+    return e_lv[:ne].copy(), e_it[:ne].copy(), e_off[:ne + 1].copy(), e_nb[:e_off[ne]].copy(), entry.value, ml.value
+
+
 # ---------------------------------------------------------------------------------------------
 # The offline all-users job: src/scala/com/twitter/simclusters_v2/scio/bq_generation/sql/tweets_ann.sql:1-64, restated
 # step by step in plain Python (small inputs only).  It is the reference's only INDEPENDENT statement of the

@@ -22,6 +22,7 @@
 // products and sums, lane j of 8 sums chunks j, j+8, ... of 8 consecutive elements, then a pairwise
 // butterfly (xor 1, 2, 4).  Compiled with -ffp-contract=off, so host (builder) == device == oracle.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -183,8 +184,8 @@ struct SearchArgs {
 };
 
 // distances of nu nodes (ids in nodes[], LDS) to the wave's query; results to dists[] (LDS)
-template <int CH>  // chunks of 8 halves per lane: dpad / 64
-__device__ __forceinline__ void wave_distances(const SearchArgs &a, const float (&qv)[CH][8], const uint32_t *nodes,
+template <int CH, class Args>  // chunks of 8 halves per lane: dpad / 64; Args = SearchArgs or BuildArgs (x, dpad, metric)
+__device__ __forceinline__ void wave_distances(const Args &a, const float (&qv)[CH][8], const uint32_t *nodes,
                                                float *dists, int nu, int lane) {
   const int g = lane >> 3, j = lane & 7;
   for (int base = 0; base < nu; base += 32) {  // up to 4 rounds of 8 vectors in flight
@@ -382,40 +383,61 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Batched index construction on the device (hnsw_index_build_insert_gpu).
+// Batched index construction on the device (hnsw_index_build_insert_gpu): every step on the GPU, and deterministic.
 //
 // The reference inserts one item at a time, and with several writer threads it accepts what that costs: "when using
-// concurrent writers we can miss connections that we would otherwise get" (HnswIndex.java:376-380).  The device
-// builder is that mode taken wide: a batch of items searches one snapshot of the graph (the walk kernel above, with
-// beam efConstruction), every item picks its neighbours by the reference's heuristic
-// (selectNearestNeighboursByHeuristic, :479-526), and the back links are applied per TARGET node -- all additions to one
-// node by one wave, which appends while the list has room (:414-417) and otherwise re-selects by the same heuristic over
-// the old list plus the additions (:419-427) -- so no two waves ever write one list and nothing needs a lock.  Items of
-// one batch do not see each other; the graph is therefore not the sequential one (nor is the reference's with two
-// writers), and its quality is checked the way such a graph can be: recall against the exhaustive search.
-// One wave per task.  Task = (base node, candidate list): candidates ascending by distance to the base.
+// concurrent writers we can miss connections that we would otherwise get" (HnswIndex.java:376-380).  The device builder is
+// that mode taken wide, with the interleaving FIXED so that two builds of one input give one graph (and so that
+// oracle/hnsw_oracle.c can restate it: oracle_hnsw_build_batched, compared entry for entry in tests/test_hnsw_gpu_build_gpu.py):
+//   order    items by (level descending, position ascending); the first is the entry point and fixes maxLevel for good
+//   rounds   round r inserts the next min(batch, max(1, linked / 8)) items of the order against ONE snapshot of the graph
+//   phase A  one wave per item (hnsw_build_insert_kernel): wireConnectionForAllLayers (:137-148) as the reference writes it --
+//            bestEntryPointUntilLayer, then per layer searchLayerForCandidates with beam efConstruction,
+//            selectNearestNeighboursByHeuristic(candidates, maxM), setConnectionList of the NEW item, neighbours.get(0)
+//            as the next layer's entry -- but the back links are only recorded: keys (layer, neighbour, order index)
+//   sort     the round's keys (hipcub radix sort): all additions to one (layer, node) become one run, in order-index order
+//   phase B  one wave per run (hnsw_build_backlink_kernel): append while the list has room (:414-417), else ONE re-selection
+//            by the heuristic over the old list followed by the additions, ascending by (Float.compare distance, position)
+//            (:419-427 does it once per addition; a round does it once per node)
+// No two waves ever write one list, nothing needs a lock or an atomic, nothing returns to the host between rounds.
+// Items of one round do not see each other; the graph is therefore not the sequential one (nor is the reference's with two
+// writers).  Two bounds the reference does not have, both counted (hnsw_index_build_stats): the candidate queue of a walk
+// holds BUILD_CCAP entries -- when full, entries farther than the current bound (which can never be expanded: the walk
+// stops at the first such entry, :589-591) are dropped and the heap is rebuilt in array order; a re-selection sees the first
+// LINK_CAP entries of old list + additions.
 // ---------------------------------------------------------------------------------------------
-struct LinkArgs {
+constexpr int BUILD_EF_MAX = 256;  // efConstruction
+constexpr int BUILD_CCAP = 1024;   // candidate-queue entries of a construction walk
+constexpr int LINK_CAP = 1024;     // old list + additions a re-selection can see
+
+struct BuildArgs {
   const _Float16 *x;
   uint32_t *adj0;              // [n][m0 + 1], updated in place
-  int32_t dpad, chunks, metric, m0;
-  // mode 0: new items.  base = targets[task]; candidates = the walk's results (positions, ascending)
-  const int64_t *cand_ids;     // [tasks][cand_stride]
-  const float *cand_dist;
-  const int32_t *cand_cnt;
-  int32_t cand_stride, max_keep;
-  uint32_t first_item;
-  uint32_t *sel;               // [tasks][max_keep + 1]: count, chosen neighbours (for the host's grouping)
-  // mode 1: back links.  base = targets[task]; additions[add_off[task] .. add_off[task+1])
-  const uint32_t *targets;
-  const uint32_t *add_off;
-  const uint32_t *additions;
+  const int32_t *upper_slot;
+  const int32_t *upper_base;
+  uint32_t *upper_adj;         // [rows][m + 1], updated in place
+  const uint32_t *order;       // [n] insertion order
+  const int32_t *levels;       // [n]
+  const int64_t *pair_off;     // [n + 1] by order index: first key slot of an item ((layers wired) * m slots each)
+  uint64_t *keys;              // the round's keys: phase A writes (unsorted buffer), phase B reads (sorted buffer)
+  uint32_t *visited;           // [round items][vwords]
+  unsigned long long *bstats;  // [0] additions a re-selection did not see, [1] candidate-queue prunes, [2] candidates dropped after a prune
+  int64_t vwords;              // a multiple of 256
+  int32_t dpad, metric, m, m0, efc, max_level;
+  int32_t ccap;                // candidate-queue entries a walk may hold: BUILD_CCAP (smaller only for tests)
+  uint32_t entry, at, count;   // the round = order[at .. at + count)
+  uint32_t n_keys;
 };
 
-// distance between stored rows a and b by the 8 lanes of a group (j = lane & 7), the walk's arithmetic; every lane of
-// the group returns the sum
+__device__ __forceinline__ uint32_t *layer_row(const BuildArgs &a, int level, uint32_t node) {
+  if (level == 0) return a.adj0 + (size_t)node * (a.m0 + 1);
+  return a.upper_adj + (size_t)(a.upper_base[a.upper_slot[node]] + level - 1) * (a.m + 1);  // (a node listed on a layer has that layer)
+}
+
+// distance between stored rows ra and rb by the 8 lanes of a group (j = lane & 7), the walk's arithmetic with row ra as the
+// query; every lane of the group returns the sum
 template <int CH>
-__device__ __forceinline__ float group_row_distance(const LinkArgs &a, uint32_t ra, uint32_t rb, int j) {
+__device__ __forceinline__ float group_row_distance(const BuildArgs &a, uint32_t ra, uint32_t rb, int j) {
   const half8 *pa = (const half8 *)(a.x + (size_t)ra * a.dpad), *pb = (const half8 *)(a.x + (size_t)rb * a.dpad);
   float acc = 0.0f;
 #pragma unroll
@@ -438,122 +460,265 @@ __device__ __forceinline__ float group_row_distance(const LinkArgs &a, uint32_t 
   return finish_distance(a.metric, acc);
 }
 
-constexpr int LINK_CAND = 256;  // candidates a task can hold (efConstruction <= 256; a target's old list + additions <= 192)
-
-template <int CH, int MODE>
-__global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
-  __shared__ uint32_t c_id[LINK_CAND];
-  __shared__ float c_d[LINK_CAND];
-  __shared__ uint32_t t_id[LINK_CAND];
-  __shared__ float t_d[LINK_CAND];
-  __shared__ uint32_t kept[2 * MAX_M];
-  const int lane = threadIdx.x, g = lane >> 3, j = lane & 7;
-  const int task = blockIdx.x;
-  uint32_t base;
-  int n = 0, max_keep;
-  if (MODE == 0) {
-    base = a.targets[task];
-    max_keep = a.max_keep;
-    n = a.cand_cnt[task];
-    n = n < LINK_CAND ? n : LINK_CAND;
-    for (int i = lane; i < n; i += 64) {
-      c_id[i] = (uint32_t)a.cand_ids[(size_t)task * a.cand_stride + i];
-      c_d[i] = a.cand_dist[(size_t)task * a.cand_stride + i];
-    }
-    __syncthreads();
-  } else {
-    base = a.targets[task];
-    max_keep = a.m0;
-    uint32_t *row = a.adj0 + (size_t)base * (a.m0 + 1);
-    const int old_n = (int)row[0];
-    const int add_n = (int)(a.add_off[task + 1] - a.add_off[task]);
-    if (old_n + add_n <= a.m0) {  // room: append (:414-417)
-      for (int i = lane; i < add_n; i += 64) row[1 + old_n + i] = a.additions[a.add_off[task] + i];
-      __syncthreads();
-      if (lane == 0) row[0] = (uint32_t)(old_n + add_n);
-      return;
-    }
-    n = old_n + add_n;
-    n = n < LINK_CAND ? n : LINK_CAND;
-    for (int i = lane; i < n; i += 64) t_id[i] = i < old_n ? row[1 + i] : a.additions[a.add_off[task] + (i - old_n)];
-    __syncthreads();
-    // distances to the base, eight candidates per round
-    for (int i0 = 0; i0 < n; i0 += 8) {
-      const int i = i0 + g;
-      float d = 0.0f;
-      if (i < n) d = group_row_distance<CH>(a, base, t_id[i], j);
-      if (i < n && j == 0) t_d[i] = d;
-    }
-    __syncthreads();
-    // ascending by (distance, position): every lane ranks its candidates by counting
-    for (int i = lane; i < n; i += 64) {
-      const float d = t_d[i];
-      int rank = 0;
-      for (int e = 0; e < n; ++e) {
-        const float o = t_d[e];
-        rank += (o < d || (o == d && e < i)) ? 1 : 0;
-      }
-      c_id[rank] = t_id[i];
-      c_d[rank] = d;
-    }
-    __syncthreads();
+// `kept` (nk entries) vs candidate c at distance dc from the base: is some kept node closer to c than the base is (:508-519)
+template <int CH>
+__device__ __forceinline__ bool heuristic_drops(const BuildArgs &a, const uint32_t *kept, int nk, uint32_t c, float dc, int lane) {
+  const int g = lane >> 3, j = lane & 7;
+  bool drop = false;
+  for (int k0 = 0; k0 < nk && !drop; k0 += 8) {
+    const int k = k0 + g;
+    bool closer = false;
+    if (k < nk) closer = group_row_distance<CH>(a, kept[k], c, j) < dc;
+    drop = __ballot(closer) != 0ull;
   }
-  // ---- selectNearestNeighboursByHeuristic: closest first; a candidate is dropped if some kept node is closer to it
-  //      than the base is (:508-519) -------------------------------------------------------------------------------
-  int nk = 0;
-  if (n <= max_keep) {  // (:488-491) everything, except the base itself
-    for (int i = 0; i < n; ++i)
-      if (c_id[i] != base) {
-        if (lane == 0) kept[nk] = c_id[i];
-        nk++;
-      }
-  } else {
-    for (int i = 0; i < n && nk < max_keep; ++i) {
-      const uint32_t c = c_id[i];
-      if (c == base) continue;
-      const float dc = c_d[i];
-      bool drop = false;
-      for (int k0 = 0; k0 < nk && !drop; k0 += 8) {
-        const int k = k0 + g;
-        bool closer = false;
-        if (k < nk) closer = group_row_distance<CH>(a, kept[k], c, j) < dc;
-        drop = __ballot(closer) != 0ull;
-      }
-      if (!drop) {
-        if (lane == 0) kept[nk] = c;
-        nk++;
+  return drop;
+}
+
+template <int CH>
+__global__ __launch_bounds__(64) void hnsw_build_insert_kernel(BuildArgs a) {
+  __shared__ HEntry wq[BUILD_EF_MAX + 1];
+  __shared__ HEntry cq[BUILD_CCAP];
+  __shared__ uint32_t ul[64];
+  __shared__ float ud[64];
+  __shared__ uint32_t kept[MAX_M];
+  const int lane = threadIdx.x;
+  const uint32_t t = blockIdx.x;
+  const uint32_t item = a.order[a.at + t];
+  const int item_level = a.levels[item];
+  uint32_t *vis = a.visited + (size_t)t * a.vwords;
+  unsigned long long n_prune = 0, n_dropped = 0;
+
+  float qv[CH][8];  // the item's own stored row is the query (distFnIndex, item to item)
+  {
+    const half8 *qrow = (const half8 *)(a.x + (size_t)item * a.dpad);
+    const int j = lane & 7;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const half8 v = qrow[j + 8 * c];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[c][e] = (float)v[e];
+    }
+  }
+  // ---- bestEntryPointUntilLayer(entry, item, maxLayer, itemLevel) (:447-475), when itemLevel < maxLayer (:140-142) ----
+  uint32_t cur = a.entry;
+  if (item_level < a.max_level) {
+    if (lane == 0) ul[0] = cur;
+    __syncthreads();
+    wave_distances<CH>(a, qv, ul, ud, 1, lane);
+    __syncthreads();
+    float cur_dist = ud[0];
+    for (int level = a.max_level; level > item_level; --level) {
+      bool changed = true;
+      while (changed) {
+        changed = false;
+        const uint32_t *row = layer_row(a, level, cur);
+        const int cnt = (int)row[0];
+        if (lane < cnt) ul[lane] = row[1 + lane];
+        __syncthreads();
+        if (cnt > 0) {
+          wave_distances<CH>(a, qv, ul, ud, cnt, lane);
+          __syncthreads();
+          for (int i = 0; i < cnt; ++i) {
+            const float d = ud[i];
+            if (d < cur_dist) {
+              cur_dist = d;
+              cur = ul[i];
+              changed = true;
+            }
+          }
+        }
         __syncthreads();
       }
     }
   }
-  __syncthreads();
-  uint32_t *row = a.adj0 + (size_t)base * (a.m0 + 1);
-  for (int i = lane; i < nk; i += 64) row[1 + i] = kept[i];
-  if (lane == 0) row[0] = (uint32_t)nk;
-  if (MODE == 0) {
-    uint32_t *s = a.sel + (size_t)task * (a.max_keep + 1);
-    for (int i = lane; i < nk; i += 64) s[1 + i] = kept[i];
-    if (lane == 0) s[0] = (uint32_t)nk;
+  const int ef = a.efc;
+  const int top = item_level < a.max_level ? item_level : a.max_level;
+  uint64_t *keys = a.keys + (a.pair_off[a.at + t] - a.pair_off[a.at]);
+  for (int level = top; level >= 0; --level) {
+    // ---- searchLayerForCandidates(item, cur, efConstruction, level) (:571-623, isUpdate = false): a fresh visited set ----
+    for (int64_t w = (int64_t)lane * 4; w < a.vwords; w += 256) *(uint4 *)(vis + w) = make_uint4(0u, 0u, 0u, 0u);
+    __threadfence_block();
+    if (lane == 0) ul[0] = cur;
+    __syncthreads();
+    wave_distances<CH>(a, qv, ul, ud, 1, lane);
+    __syncthreads();
+    int cn = 0, wn = 0;
+    {
+      const HEntry e0{ud[0], cur};
+      pq_add<true>(cq, cn, e0);
+      pq_add<false>(wq, wn, e0);
+      if (lane == 0) atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+    }
+    float lower = wq[0].dist;
+    __syncthreads();
+    while (cn > 0) {
+      const HEntry cand = cq[0];
+      if (cand.dist > lower) break;
+      (void)pq_poll<true>(cq, cn);
+      const uint32_t *row = layer_row(a, level, cand.node);
+      const int cnt = (int)row[0];
+      uint32_t nn = 0;
+      bool fresh = false;
+      if (lane < cnt) {
+        nn = row[1 + lane];
+        const uint32_t bit = 1u << (nn & 31);
+        fresh = (atomicOr(&vis[nn >> 5], bit) & bit) == 0;  // visited.contains / visited.add
+      }
+      const unsigned long long mask = __ballot(fresh);
+      const int nu = __popcll(mask);
+      if (fresh) ul[__popcll(mask & ((1ull << lane) - 1))] = nn;  // list order is kept
+      __syncthreads();
+      if (nu > 0) {
+        wave_distances<CH>(a, qv, ul, ud, nu, lane);
+        __syncthreads();
+        for (int i = 0; i < nu; ++i) {
+          const HEntry e{ud[i], ul[i]};
+          if (wn < ef || e.dist < wq[0].dist) {
+            if (cn >= a.ccap) {  // drop what can never be expanded, rebuild the heap in array order
+              const int had = cn;
+              cn = 0;
+              for (int s = 0; s < had; ++s) {
+                const HEntry x = cq[s];
+                if (!(x.dist > lower)) pq_add<true>(cq, cn, x);
+              }
+              n_prune += 1;
+            }
+            if (cn < a.ccap) pq_add<true>(cq, cn, e);
+            else n_dropped += 1;
+            pq_add<false>(wq, wn, e);
+            if (wn > ef) (void)pq_poll<false>(wq, wn);
+            lower = wq[0].dist;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // ---- selectNearestNeighboursByHeuristic(candidates, maxM) (:479-526); the item itself is never among them ----
+    int nk = 0;
+    if (wn <= a.m) {  // (:488-491) toListWithItem: the queue's ARRAY order
+      if (lane < wn) kept[lane] = wq[lane].node;
+      nk = wn;
+      __syncthreads();
+    } else {
+      cn = 0;  // candidates.reverse() (:495): re-offered in array order under the reversed comparator
+      for (int i = 0; i < wn; ++i) pq_add<true>(cq, cn, wq[i]);
+      __syncthreads();
+      while (cn > 0 && nk < a.m) {
+        const HEntry c = pq_poll<true>(cq, cn);
+        if (!heuristic_drops<CH>(a, kept, nk, c.node, c.dist, lane)) {
+          if (lane == 0) kept[nk] = c.node;
+          nk++;
+          __syncthreads();
+        }
+      }
+    }
+    // ---- setConnectionList(item, level, neighbours) (:393); the back links become keys ----
+    uint32_t *row = layer_row(a, level, item);
+    if (lane < nk) row[1 + lane] = kept[lane];
+    if (lane == 0) row[0] = (uint32_t)nk;
+    uint64_t *kslot = keys + (size_t)(top - level) * a.m;
+    if (lane < a.m)
+      kslot[lane] = lane < nk ? ((uint64_t)level << 56) | ((uint64_t)kept[lane] << 24) | (uint64_t)t : ~0ull;
+    cur = kept[0];  // neighbours.get(0) (:439)
+    __syncthreads();
+  }
+  if (lane == 0 && (n_prune | n_dropped)) {
+    atomicAdd(&a.bstats[1], n_prune);
+    atomicAdd(&a.bstats[2], n_dropped);
   }
 }
 
 template <int CH>
-int launch_link(int mode, int tasks, const LinkArgs &a, hipStream_t st) {
-  if (tasks <= 0) return HNSW_OK;
-  if (mode == 0) hipLaunchKernelGGL((hnsw_link_kernel<CH, 0>), dim3(tasks), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL((hnsw_link_kernel<CH, 1>), dim3(tasks), dim3(64), 0, st, a);
-  return HNSW_OK;
+__global__ __launch_bounds__(64) void hnsw_build_backlink_kernel(BuildArgs a) {
+  __shared__ uint32_t t_id[LINK_CAP];
+  __shared__ float t_d[LINK_CAP];
+  __shared__ uint32_t c_id[LINK_CAP];
+  __shared__ float c_d[LINK_CAP];
+  __shared__ uint32_t kept[2 * MAX_M];
+  const int lane = threadIdx.x, g = lane >> 3, j = lane & 7;
+  const uint32_t i0 = blockIdx.x;
+  const uint64_t key = a.keys[i0];
+  if (key == ~0ull) return;
+  const uint64_t run = key >> 24;  // (layer, node)
+  if (i0 > 0 && (a.keys[i0 - 1] >> 24) == run) return;  // not the head of its run
+  const int level = (int)(key >> 56);
+  const uint32_t base = (uint32_t)(run & 0xffffffffull);
+  int add_n = 0;
+  for (uint32_t b = i0;; b += 64) {
+    const uint32_t idx = b + lane;
+    const bool same = idx < a.n_keys && (a.keys[idx] >> 24) == run;
+    const unsigned long long mask = __ballot(same);
+    if (mask == ~0ull) {
+      add_n += 64;
+      continue;
+    }
+    add_n += __builtin_ctzll(~mask);
+    break;
+  }
+  const int M = level == 0 ? a.m0 : a.m;
+  uint32_t *row = layer_row(a, level, base);
+  const int old_n = (int)row[0];
+  if (old_n + add_n <= M) {  // room: append, in order-index order (:414-417)
+    for (int i = lane; i < add_n; i += 64) row[1 + old_n + i] = a.order[a.at + (uint32_t)(a.keys[i0 + i] & 0xffffffull)];
+    __syncthreads();
+    if (lane == 0) row[0] = (uint32_t)(old_n + add_n);
+    return;
+  }
+  int n = old_n + add_n;
+  if (n > LINK_CAP) {
+    if (lane == 0) atomicAdd(&a.bstats[0], (unsigned long long)(n - LINK_CAP));
+    n = LINK_CAP;
+  }
+  for (int i = lane; i < n; i += 64) t_id[i] = i < old_n ? row[1 + i] : a.order[a.at + (uint32_t)(a.keys[i0 + (i - old_n)] & 0xffffffull)];
+  __syncthreads();
+  for (int r0 = 0; r0 < n; r0 += 8) {  // distances to the base, eight candidates per round
+    const int i = r0 + g;
+    float d = 0.0f;
+    if (i < n) d = group_row_distance<CH>(a, base, t_id[i], j);
+    if (i < n && j == 0) t_d[i] = d;
+  }
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) {  // ascending by (Float.compare distance, position): every lane ranks its candidates by counting
+    const float d = t_d[i];
+    int rank = 0;
+    for (int e = 0; e < n; ++e) {
+      const int c = float_compare(t_d[e], d);
+      rank += (c < 0 || (c == 0 && e < i)) ? 1 : 0;
+    }
+    c_id[rank] = t_id[i];
+    c_d[rank] = d;
+  }
+  __syncthreads();
+  int nk = 0;  // n > M here: the heuristic proper (:495-523)
+  for (int i = 0; i < n && nk < M; ++i) {
+    const uint32_t c = c_id[i];
+    if (c == base) continue;
+    if (!heuristic_drops<CH>(a, kept, nk, c, c_d[i], lane)) {
+      if (lane == 0) kept[nk] = c;
+      nk++;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < nk; i += 64) row[1 + i] = kept[i];
+  if (lane == 0) row[0] = (uint32_t)nk;
 }
-int launch_link_any(int chunks, int mode, int tasks, const LinkArgs &a, hipStream_t st) {
+
+template <int CH>
+void launch_build_round(const BuildArgs &a_ins, const BuildArgs &a_link, hipStream_t st, int which) {
+  if (which == 0) hipLaunchKernelGGL((hnsw_build_insert_kernel<CH>), dim3(a_ins.count), dim3(64), 0, st, a_ins);
+  else hipLaunchKernelGGL((hnsw_build_backlink_kernel<CH>), dim3(a_link.n_keys), dim3(64), 0, st, a_link);
+}
+void launch_build_any(int chunks, const BuildArgs &a_ins, const BuildArgs &a_link, hipStream_t st, int which) {
   switch (chunks) {
-    case 1: return launch_link<1>(mode, tasks, a, st);
-    case 2: return launch_link<2>(mode, tasks, a, st);
-    case 3: return launch_link<3>(mode, tasks, a, st);
-    case 4: return launch_link<4>(mode, tasks, a, st);
-    case 5: return launch_link<5>(mode, tasks, a, st);
-    case 6: return launch_link<6>(mode, tasks, a, st);
-    case 7: return launch_link<7>(mode, tasks, a, st);
-    default: return launch_link<8>(mode, tasks, a, st);
+    case 1: return launch_build_round<1>(a_ins, a_link, st, which);
+    case 2: return launch_build_round<2>(a_ins, a_link, st, which);
+    case 3: return launch_build_round<3>(a_ins, a_link, st, which);
+    case 4: return launch_build_round<4>(a_ins, a_link, st, which);
+    case 5: return launch_build_round<5>(a_ins, a_link, st, which);
+    case 6: return launch_build_round<6>(a_ins, a_link, st, which);
+    case 7: return launch_build_round<7>(a_ins, a_link, st, which);
+    default: return launch_build_round<8>(a_ins, a_link, st, which);
   }
 }
 
@@ -605,6 +770,7 @@ struct hnsw_index {
   int64_t last_peak = 0;
   int8_t tier_hint[MAX_EF + 1] = {};  // [beam]: 1 + the LDS tier at which the next search of that beam width starts (0 = none yet)
   float last_ms = 0;
+  int64_t build_rounds = 0, build_truncated = 0, build_prunes = 0, build_dropped = 0;  // hnsw_index_build_insert_gpu
   ~hnsw_index() {
     for (auto &e : ev)
       if (e) (void)hipEventDestroy(e);
@@ -1087,165 +1253,138 @@ static int build_insert_impl(int32_t device, int32_t metric, int64_t n, int32_t 
   return HNSW_OK;
 }
 
-// Construction on the device.  Items with a level above 0 (one in maxM) go in first, on the host, one by one as
-// the reference does -- that fixes the entry point and every upper layer -- and the rest, which only ever touch layer 0,
-// in batches on the GPU (see hnsw_link_kernel).  batch = items per round (0 = 4096; a round never holds more than an
-// eighth of the graph it searches, so early rounds are small).
-int hnsw_index_build_insert_gpu(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
-                                int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t batch, hnsw_index_t **out) try {
+// Construction on the device: see the comment above hnsw_build_insert_kernel.  The host only works out the insertion
+// order and the round schedule (both functions of the levels alone) and enqueues kernels; nothing comes back before the end.
+static int build_insert_gpu_impl(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                                 int32_t max_m, int32_t ef_construction, uint64_t seed, const int32_t *given_levels, int32_t batch,
+                                 hnsw_index_t **out) {
   if (!out) return fail(HNSW_EINVAL, "out is NULL");
-  if (ef_construction < 1 || ef_construction > LINK_CAND) return fail(HNSW_EINVAL, "ef_construction must be in 1..256");
-  if (batch < 0) return fail(HNSW_EINVAL, "batch must not be negative");
+  if (ef_construction < 1 || ef_construction > BUILD_EF_MAX) return fail(HNSW_EINVAL, "ef_construction must be in 1..256");
+  if (batch < 0 || batch > (1 << 20)) return fail(HNSW_EINVAL, "batch must be in 0..2^20");
   if (batch == 0) batch = 4096;
   std::unique_ptr<hnsw_index> ix;
-  std::vector<float> rows;
-  int rc = create_index(device, metric, n, d, vectors, nullptr, max_m, ix, &rows);  // (positions as labels while building)
+  int rc = create_index(device, metric, n, d, vectors, nullptr, max_m, ix, nullptr);  // (positions as labels while building)
   if (rc) return rc;
   const double level_mult = 1.0 / std::log(1.0 * max_m);  // HnswIndex.java:118
   std::vector<int32_t> levels((size_t)n);
   for (int64_t i = 0; i < n; ++i) {
+    if (given_levels) {
+      if (given_levels[i] < 0 || given_levels[i] > 60) return fail(HNSW_EINVAL, "a level is outside 0..60");
+      levels[(size_t)i] = given_levels[i];
+      continue;
+    }
     const uint64_t h = sann::mix64(seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull));
     const double u = ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740992.0);  // (0, 1]
     levels[(size_t)i] = std::min(60, (int)(-std::log(u) * level_mult));       // getRandomLevel, :369-371
   }
-  // ---- host: the items of the upper layers, and enough of the others for the first device rounds to have a graph -----
+  // the empty graph with every row in place (rows are a function of the levels); the kernels fill it
   HostGraph g;
   g.init(n, max_m, levels);
-  HostVectors hv;
-  hv.load(rows, n, ix->dpad, metric);
-  rows.clear();
-  rows.shrink_to_fit();
-  std::vector<uint8_t> done((size_t)n, 0);
-  {
-    std::vector<uint32_t> first;
-    for (int64_t i = 0; i < n; ++i)
-      if (levels[(size_t)i] > 0) { first.push_back((uint32_t)i); done[(size_t)i] = 1; }
-    for (int64_t i = 0; i < n && (int64_t)first.size() < std::min<int64_t>(n, 1024); ++i)
-      if (!done[(size_t)i]) { first.push_back((uint32_t)i); done[(size_t)i] = 1; }
-    // (as hnsw_index_build_insert: the first few one by one, the rest by a pool of writers under per-item locks)
-    const size_t warm = std::min<size_t>(first.size(), 256);
-    {
-      Builder b{g, hv, ef_construction, std::vector<uint32_t>((size_t)n, 0), 0};
-      for (size_t t = 0; t < warm; ++t) b.insert(first[t], levels[(size_t)first[t]]);
-    }
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())),
-                                                            (first.size() - warm) / 64));
-    std::atomic<size_t> next(warm);
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nt && warm < first.size(); ++t)
-      pool.emplace_back([&]() {
-        Builder b{g, hv, ef_construction, std::vector<uint32_t>((size_t)n, 0), 0};
-        for (;;) {
-          const size_t e = next.fetch_add(1);
-          if (e >= first.size()) break;
-          b.insert(first[e], levels[(size_t)first[e]]);
-        }
-      });
-    for (auto &th : pool) th.join();
+  std::vector<uint32_t> order((size_t)n);
+  for (int64_t i = 0; i < n; ++i) order[(size_t)i] = (uint32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return levels[x] > levels[y]; });
+  if (n > 0) {
+    g.entry = order[0];
+    g.max_level = levels[order[0]];
   }
   rc = upload_graph(ix.get(), g);
   if (rc) return rc;
-  // ---- device: the rest, layer 0 only, in rounds ---------------------------------------------------------------------
-  std::vector<uint32_t> todo;
-  for (int64_t i = 0; i < n; ++i)
-    if (!done[(size_t)i]) todo.push_back((uint32_t)i);
-  int64_t in_graph = n - (int64_t)todo.size();
-  HTRY(hipSetDevice(device));
-  const int k_walk = ef_construction;
-  Buf d_sel, d_targets, d_addoff, d_adds, d_cand_ids, d_cand_dist, d_cand_cnt;
-  std::vector<float> q, w_dist;
-  std::vector<int64_t> w_ids;
-  std::vector<int32_t> w_cnt;
-  std::vector<uint32_t> sel, targets, add_off, adds;
-  std::vector<std::pair<uint32_t, uint32_t>> pairs;  // (target, new item)
-  size_t at = 0;
-  while (at < todo.size()) {
-    const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(batch, in_graph / 8));
-    const size_t m = (size_t)std::min<int64_t>(cap, (int64_t)(todo.size() - at));
-    // the round's items as queries (their original rows: hnsw_search prepares them exactly as the stored ones were)
-    q.resize(m * (size_t)d);
-    for (size_t t = 0; t < m; ++t) std::memcpy(&q[t * d], vectors + (size_t)todo[at + t] * d, (size_t)d * sizeof(float));
-    w_dist.resize(m * (size_t)k_walk);
-    w_ids.resize(m * (size_t)k_walk);
-    w_cnt.resize(m);
-    rc = hnsw_search(ix.get(), (int32_t)m, q.data(), k_walk, ef_construction, w_dist.data(), w_ids.data(), w_cnt.data());
-    if (rc) return rc;
-    // items are not contiguous in position: the link kernel takes explicit bases through a one-entry "targets" list
-    HTRY(d_cand_ids.reserve(m * (size_t)k_walk * 8));
-    HTRY(d_cand_dist.reserve(m * (size_t)k_walk * 4));
-    HTRY(d_cand_cnt.reserve(m * 4));
-    HTRY(hipMemcpy(d_cand_ids.p, w_ids.data(), m * (size_t)k_walk * 8, hipMemcpyHostToDevice));
-    HTRY(hipMemcpy(d_cand_dist.p, w_dist.data(), m * (size_t)k_walk * 4, hipMemcpyHostToDevice));
-    HTRY(hipMemcpy(d_cand_cnt.p, w_cnt.data(), m * 4, hipMemcpyHostToDevice));
-    HTRY(d_targets.reserve(std::max<size_t>(m, 1) * 4));
-    HTRY(hipMemcpy(d_targets.p, todo.data() + at, m * 4, hipMemcpyHostToDevice));
-    HTRY(d_sel.reserve(m * (size_t)(max_m + 1) * 4));
-    LinkArgs a;
+  ix->build_truncated = ix->build_prunes = ix->build_dropped = ix->build_rounds = 0;
+  if (n > 1) {
+    HTRY(hipSetDevice(device));
+    const int max_level = ix->max_level;
+    std::vector<int64_t> pair_off((size_t)n + 1, 0);
+    for (int64_t e = 0; e < n; ++e) pair_off[(size_t)e + 1] = pair_off[(size_t)e] + (int64_t)(std::min(levels[order[(size_t)e]], max_level) + 1) * max_m;
+    // the schedule: rounds of min(batch, max(1, linked / 8)) items
+    std::vector<std::pair<int64_t, int64_t>> rounds;
+    int64_t max_keys = 0, max_items = 0;
+    for (int64_t at = 1, linked = 1; at < n;) {
+      const int64_t m = std::min<int64_t>(n - at, std::min<int64_t>(batch, std::max<int64_t>(1, linked / 8)));
+      rounds.emplace_back(at, m);
+      max_keys = std::max(max_keys, pair_off[(size_t)(at + m)] - pair_off[(size_t)at]);
+      max_items = std::max(max_items, m);
+      at += m;
+      linked += m;
+    }
+    if (max_keys >= (int64_t)1 << 31) return fail(HNSW_EINVAL, "batch * max_m too large");
+    Buf d_order, d_levels, d_pair_off, d_keys, d_sorted, d_tmp, d_bstats, d_visited;
+    HTRY(d_order.reserve((size_t)n * 4));
+    HTRY(d_levels.reserve((size_t)n * 4));
+    HTRY(d_pair_off.reserve(((size_t)n + 1) * 8));
+    HTRY(hipMemcpy(d_order.p, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HTRY(hipMemcpy(d_levels.p, levels.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HTRY(hipMemcpy(d_pair_off.p, pair_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+    HTRY(d_keys.reserve((size_t)max_keys * 8));
+    HTRY(d_sorted.reserve((size_t)max_keys * 8));
+    HTRY(d_bstats.reserve(4 * 8));
+    HTRY(hipMemset(d_bstats.p, 0, 4 * 8));
+    const int64_t vwords = ((n + 31) / 32 + 255) / 256 * 256;
+    HTRY(d_visited.reserve((size_t)max_items * vwords * 4));
+    size_t tmp_bytes = 0;
+    HTRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys.as<uint64_t>(), d_sorted.as<uint64_t>(), (int)max_keys, 0, 64, (hipStream_t)0));
+    HTRY(d_tmp.reserve(tmp_bytes));
+    BuildArgs a;
     a.x = ix->x.as<_Float16>();
     a.adj0 = ix->adj0.as<uint32_t>();
+    a.upper_slot = ix->upper_slot.as<int32_t>();
+    a.upper_base = ix->upper_base.as<int32_t>();
+    a.upper_adj = ix->upper_adj.as<uint32_t>();
+    a.order = d_order.as<uint32_t>();
+    a.levels = d_levels.as<int32_t>();
+    a.pair_off = d_pair_off.as<int64_t>();
+    a.visited = d_visited.as<uint32_t>();
+    a.bstats = d_bstats.as<unsigned long long>();
+    a.vwords = vwords;
     a.dpad = ix->dpad;
-    a.chunks = ix->dpad / 64;
     a.metric = ix->metric;
+    a.m = ix->m;
     a.m0 = ix->m0;
-    a.cand_ids = d_cand_ids.as<int64_t>();
-    a.cand_dist = d_cand_dist.as<float>();
-    a.cand_cnt = d_cand_cnt.as<int32_t>();
-    a.cand_stride = k_walk;
-    a.max_keep = max_m;  // (:392: maxM for the new item on every level)
-    a.first_item = 0;
-    a.sel = d_sel.as<uint32_t>();
-    a.targets = d_targets.as<uint32_t>();
-    a.add_off = nullptr;
-    a.additions = nullptr;
-    rc = launch_link_any(a.chunks, 0, (int)m, a, 0);
-    if (rc) return rc;
-    HTRY(hipGetLastError());
-    sel.resize(m * (size_t)(max_m + 1));
-    HTRY(hipMemcpy(sel.data(), d_sel.p, sel.size() * 4, hipMemcpyDeviceToHost));
-    // back links grouped by target: one wave per target applies all of them
-    pairs.clear();
-    for (size_t t = 0; t < m; ++t) {
-      const uint32_t *row = &sel[t * (size_t)(max_m + 1)];
-      for (uint32_t e = 0; e < row[0]; ++e) pairs.emplace_back(row[1 + e], todo[at + t]);
-    }
-    std::sort(pairs.begin(), pairs.end());
-    targets.clear();
-    add_off.assign(1, 0);
-    adds.clear();
-    for (size_t e = 0; e < pairs.size(); ++e) {
-      if (e == 0 || pairs[e].first != pairs[e - 1].first) {
-        if (e) add_off.push_back((uint32_t)adds.size());
-        targets.push_back(pairs[e].first);
-      }
-      adds.push_back(pairs[e].second);
-    }
-    add_off.push_back((uint32_t)adds.size());
-    if (!targets.empty()) {
-      HTRY(d_targets.reserve(targets.size() * 4));
-      HTRY(d_addoff.reserve(add_off.size() * 4));
-      HTRY(d_adds.reserve(adds.size() * 4));
-      HTRY(hipMemcpy(d_targets.p, targets.data(), targets.size() * 4, hipMemcpyHostToDevice));
-      HTRY(hipMemcpy(d_addoff.p, add_off.data(), add_off.size() * 4, hipMemcpyHostToDevice));
-      HTRY(hipMemcpy(d_adds.p, adds.data(), adds.size() * 4, hipMemcpyHostToDevice));
-      a.targets = d_targets.as<uint32_t>();
-      a.add_off = d_addoff.as<uint32_t>();
-      a.additions = d_adds.as<uint32_t>();
-      rc = launch_link_any(a.chunks, 1, (int)targets.size(), a, 0);
-      if (rc) return rc;
+    a.efc = ef_construction;
+    a.max_level = max_level;
+    a.ccap = BUILD_CCAP;
+    if (const char *e = std::getenv("HNSW_BUILD_CCAP")) a.ccap = std::max(2, std::min(BUILD_CCAP, std::atoi(e)));  // (tests: make the prune path run)
+    a.entry = (uint32_t)ix->entry;
+    const int chunks = ix->dpad / 64;
+    for (const auto &r : rounds) {
+      a.at = (uint32_t)r.first;
+      a.count = (uint32_t)r.second;
+      a.n_keys = (uint32_t)(pair_off[(size_t)(r.first + r.second)] - pair_off[(size_t)r.first]);
+      BuildArgs a_ins = a, a_link = a;
+      a_ins.keys = d_keys.as<uint64_t>();
+      a_link.keys = d_sorted.as<uint64_t>();
+      launch_build_any(chunks, a_ins, a_link, 0, 0);
+      size_t tb = tmp_bytes;
+      HTRY(hipcub::DeviceRadixSort::SortKeys(d_tmp.p, tb, d_keys.as<uint64_t>(), d_sorted.as<uint64_t>(), (int)a.n_keys, 0, 64, (hipStream_t)0));
+      launch_build_any(chunks, a_ins, a_link, 0, 1);
       HTRY(hipGetLastError());
     }
     HTRY(hipDeviceSynchronize());
-    at += m;
-    in_graph += (int64_t)m;
-  }
-  // ---- the finished layer 0 back to the host copy (export, files), keys attached ----------------------------------------
-  {
-    std::vector<uint32_t> adj0((size_t)std::max<int64_t>(n, 1) * (ix->m0 + 1));
+    unsigned long long bs[4] = {0, 0, 0, 0};
+    HTRY(hipMemcpy(bs, d_bstats.p, sizeof(bs), hipMemcpyDeviceToHost));
+    ix->build_truncated = (int64_t)bs[0];
+    ix->build_prunes = (int64_t)bs[1];
+    ix->build_dropped = (int64_t)bs[2];
+    ix->build_rounds = (int64_t)rounds.size();
+    // ---- the finished graph back to the host copy (export, files).  The map holds HnswNode(level, item) for every wired item
+    //      and layer; the first item was never wired (:184-186: no entry point yet) and has a key only where a back link put one
+    std::vector<uint32_t> adj0((size_t)n * (ix->m0 + 1));
     HTRY(hipMemcpy(adj0.data(), ix->adj0.p, adj0.size() * 4, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; ++i) {
       const uint32_t *row = &adj0[(size_t)i * (ix->m0 + 1)];
       ix->level0[(size_t)i].assign(row + 1, row + 1 + row[0]);
-      ix->has0[(size_t)i] = 1;
+      ix->has0[(size_t)i] = (row[0] > 0 || i != ix->entry) ? 1 : 0;
+    }
+    const int64_t urows = ix->upper_base_h.back();
+    std::vector<uint32_t> uadj((size_t)std::max<int64_t>(urows, 1) * (ix->m + 1));
+    if (urows > 0) HTRY(hipMemcpy(uadj.data(), ix->upper_adj.p, (size_t)urows * (ix->m + 1) * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t sl = ix->upper_slot_h[(size_t)i];
+      if (sl < 0) continue;
+      for (int l = 1; l <= levels[(size_t)i]; ++l) {
+        const uint32_t *row = uadj.data() + (size_t)(ix->upper_base_h[(size_t)sl] + l - 1) * (ix->m + 1);
+        ix->upper[(size_t)l - 1][(size_t)sl].assign(row + 1, row + 1 + row[0]);
+        ix->has_upper[(size_t)sl][(size_t)l - 1] = (row[0] > 0 || i != ix->entry) ? 1 : 0;
+      }
     }
   }
   if (ids && n > 0) {
@@ -1254,6 +1393,26 @@ int hnsw_index_build_insert_gpu(int32_t device, int32_t metric, int64_t n, int32
     ix->has_ids = true;
   }
   *out = ix.release();
+  return HNSW_OK;
+}
+
+int hnsw_index_build_insert_gpu(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                                int32_t max_m, int32_t ef_construction, uint64_t seed, int32_t batch, hnsw_index_t **out) try {
+  return build_insert_gpu_impl(device, metric, n, d, vectors, ids, max_m, ef_construction, seed, nullptr, batch, out);
+} ABI_CATCH
+
+int hnsw_index_build_insert_gpu_levels(int32_t device, int32_t metric, int64_t n, int32_t d, const float *vectors, const int64_t *ids,
+                                       int32_t max_m, int32_t ef_construction, const int32_t *levels, int32_t batch, hnsw_index_t **out) try {
+  if (!levels && n > 0) return fail(HNSW_EINVAL, "levels is NULL");
+  return build_insert_gpu_impl(device, metric, n, d, vectors, ids, max_m, ef_construction, 0, levels, batch, out);
+} ABI_CATCH
+
+int hnsw_index_build_stats(const hnsw_index_t *ix, int64_t *rounds, int64_t *unseen_additions, int64_t *queue_prunes, int64_t *dropped_candidates) try {
+  if (!ix) return fail(HNSW_EINVAL, "NULL index");
+  if (rounds) *rounds = ix->build_rounds;
+  if (unseen_additions) *unseen_additions = ix->build_truncated;
+  if (queue_prunes) *queue_prunes = ix->build_prunes;
+  if (dropped_candidates) *dropped_candidates = ix->build_dropped;
   return HNSW_OK;
 } ABI_CATCH
 

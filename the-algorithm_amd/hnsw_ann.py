@@ -27,6 +27,9 @@ PROTOS = {
                                                  C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "hnsw_index_build_insert_gpu": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                               C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "hnsw_index_build_insert_gpu_levels": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                     C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "hnsw_index_build_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "hnsw_index_graph_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "hnsw_index_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hnsw_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -84,6 +87,13 @@ class Hnsw:
         v = np.ascontiguousarray(vectors, np.float32)
         i = None if ids is None else np.ascontiguousarray(ids, np.int64)
         h = C.c_void_p()
+        if gpu and levels is not None:
+            lv = np.ascontiguousarray(levels, np.int32)
+            if lv.shape != (v.shape[0],):
+                raise ValueError("levels must hold one level per vector")
+            _check(lib, lib.hnsw_index_build_insert_gpu_levels(device, int(metric), v.shape[0], v.shape[1], _p(v), _p(i), max_m,
+                                                               ef_construction, _p(lv), batch, C.byref(h)))
+            return cls(h, metric, v.shape[0], v.shape[1], max_m)
         if gpu:  # batched construction on the device (hnsw_index_build_insert_gpu)
             _check(lib, lib.hnsw_index_build_insert_gpu(device, int(metric), v.shape[0], v.shape[1], _p(v), _p(i), max_m,
                                                         ef_construction, seed, batch, C.byref(h)))
@@ -149,6 +159,12 @@ class Hnsw:
     def query(self, embedding: np.ndarray, numOfNeighbors: int, runtimeParams: HnswParams) -> List[int]:
         """Hnsw.scala:95-116."""
         return [i for i, _ in self.queryWithDistance(embedding, numOfNeighbors, runtimeParams)]
+
+    def build_stats(self):
+        """Counters of the device build: (rounds, additions a re-selection did not see, candidate-queue prunes, dropped candidates)."""
+        v = [C.c_int64() for _ in range(4)]
+        _check(_lib(), _lib().hnsw_index_build_stats(self._h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     def last_stats(self):
         lib = _lib()
