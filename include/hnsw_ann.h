@@ -116,6 +116,9 @@ int hnsw_search(hnsw_index_t *index, int32_t nq, const float *queries, int32_t k
  * global-memory queues, and the kernel time (HIP events, ms). */
 int hnsw_last_stats(const hnsw_index_t *index, int64_t *distance_evals, int64_t *expansions, int32_t *spilled_queries,
                     float *kernel_ms);
+/* More counters of the last hnsw_search: neighbours admitted to the queues (each costs an offer to both queues and, once the
+ * result queue is full, a poll), and the largest candidate queue any query of the batch reached. */
+int hnsw_last_walk_counters(const hnsw_index_t *index, int64_t *admissions, int64_t *largest_candidate_queue);
 
 #ifdef __cplusplus
 }

@@ -92,16 +92,18 @@ def test_large_beam_and_the_global_queue_path(pkg, oracle):
     q = rng.standard_normal((12, 16)).astype(np.float32)
     _compare(pkg, oracle, ix, m, q, 100, 1024)
     assert ix.last_stats()["spilled_queries"] == 0
-    # the candidate queue stays below the beam width in practice; shrink the LDS allowance to force the
-    # re-run with global-memory queues and demand the same answers
+    # the candidate queue's top is in LDS and its tail in global memory.  Shrink both (40 + 40 entries) to force the
+    # re-run with the large global part, and demand the same answers; then shrink only the LDS part, so that nearly
+    # every heap step crosses the LDS / global boundary
     import os
     os.environ["HNSW_DEBUG_CCAP"] = "40"
     try:
         _compare(pkg, oracle, ix, m, q, 100, 1024)
         assert ix.last_stats()["spilled_queries"] == len(q)
-        os.environ["HNSW_DEBUG_CCAP"] = "-40"   # same, but through the second tier (one wave with 136 KB of LDS)
-        _compare(pkg, oracle, ix, m, q, 100, 1024)
-        assert ix.last_stats()["spilled_queries"] == len(q)
+        for v in ("-40", "-1", "-7"):
+            os.environ["HNSW_DEBUG_CCAP"] = v
+            _compare(pkg, oracle, ix, m, q, 100, 1024)
+            assert ix.last_stats()["spilled_queries"] == 0
     finally:
         del os.environ["HNSW_DEBUG_CCAP"]
     with pytest.raises(pkg.hnsw_ann.HnswError):

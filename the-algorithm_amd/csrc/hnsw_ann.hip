@@ -13,9 +13,14 @@
 //   * distances of the unvisited neighbours: 8 lanes per vector (16-B loads, 128 B contiguous per
 //     group), 8 vectors per round, all rounds' loads issued before the first reduction;
 //   * then the reference's own admission loop, in list order, on the two queues.
-// The queues are java.util.PriorityQueue restated (same siftUp / siftDown), held in LDS, operated
-// wave-uniformly; that makes equal distances come out as on the JVM.  A query whose candidate queue
-// outgrows LDS is re-run with both queues in global memory (same code, GLOBALQ = true).
+// The queues are java.util.PriorityQueue restated (same siftUp / siftDown), operated wave-uniformly; that makes equal
+// distances come out as on the JVM.  What bounds the kernel is how many walks a CU holds -- a walk is one long dependent
+// chain of heap steps and gathers, a wave issues an instruction every 3-4 cycles at best (profiles/r03_pmc_c4_dense_hnsw.txt),
+// and the LDS a walk needs decides how many waves share a SIMD.  So the LDS holds what is hot and no more: the result queue
+// (beam + 1 entries; every admission sifts through it twice) and the TOP of the candidate queue; the candidate queue's tail
+// -- which an offer touches at one or two levels and only a poll (one per expansion) descends into -- lives in global
+// memory, L2-resident.  ~10 KB per walk = 16 walks per CU at any beam (round 2: 23-39 KB at beam 800, 4-7 walks per CU).
+// A query whose candidate queue outgrows the first pass's global part is re-run with a larger one.
 // HBM-latency bound by nature: every expansion is a dependent gather of <= 2*maxM random 512-B rows.
 //
 // Distance arithmetic (the fixed order oracle/hnsw_oracle.c repeats): operands rounded to fp16, fp32
@@ -56,13 +61,10 @@ int fail(int code, const std::string &m) {
 constexpr int MAX_D = 512;
 constexpr int MAX_M = 32;        // lists of <= 2*MAX_M = 64 neighbours: one lane each
 constexpr int MAX_EF = 1024;
-constexpr int CCAP_LDS = 2048;   // candidate queue entries in LDS
-constexpr int CCAP_LDS_BIG = 16384;  // last LDS tier of a query that overflowed the smaller ones: 136 KB of LDS, one wave per CU
-// LDS tiers of the candidate queue.  A query that outgrows one is run again in the next (the walk is the same, only the
-// capacity differs); the index remembers, per beam width, the largest queue the previous search saw and starts there.
-constexpr int CCAP_TIERS[] = {512, 1024, CCAP_LDS, 4096, 8192, CCAP_LDS_BIG};
-constexpr int N_CCAP_TIERS = 6;
-constexpr int CCAP_GLOBAL = 1 << 17;
+constexpr int CCAP_LDS = 1024;          // most candidate-queue entries kept in LDS (the queue's top)
+constexpr int WALK_LDS_BYTES = 9 * 1024;  // dynamic LDS of a walk: result queue + candidate-queue top (16 walks per CU with the static 0.5 KB)
+constexpr int CCAP_FIRST = 8192;        // global part of the candidate queue, first pass (64 KB per query)
+constexpr int CCAP_GLOBAL = 1 << 17;    // ... of the re-run of a query that outgrew it
 
 struct Buf {
   void *p = nullptr;
@@ -151,6 +153,125 @@ __host__ __device__ inline HEntry pq_poll(HEntry *q, int &n) {
   return result;
 }
 
+// ---- the search kernel's queues -------------------------------------------------------------------------------------
+// Entries carry the distance as an integer KEY whose signed order is Float.compare's (floatToIntBits, then the low 31
+// bits flipped for negatives: -0.0 < +0.0, NaN -- canonical -- above +inf), so a heap comparison is one integer compare.
+struct KEntry {
+  int32_t key;
+  uint32_t node;
+};
+__device__ __forceinline__ int32_t dist_key(float f) {
+  const int32_t b = float_to_int_bits(f);
+  return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float key_dist(int32_t k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+template <bool MINQ>
+__device__ __forceinline__ bool k_before(int32_t a, int32_t b) {  // comparator(a, b) < 0
+  return MINQ ? a < b : a > b;
+}
+// Every lane of the wave runs the same queue code on the same data, but a value that comes back from LDS or global memory is
+// a vector register as far as the compiler can tell, and every loop and branch that depends on it becomes exec-mask
+// bookkeeping (s_and_saveexec / s_or / s_andn2 on masks that are always all-ones: ~35 instructions per sift level in the
+// round-3 ISA).  v_readfirstlane says what we know -- the value is wave-uniform -- and counters, heap positions and
+// comparisons move to scalar registers, branches become plain s_cbranch (~25 per level).  Measured: no change in kernel time
+// (25.0 ms either way at beam 800, 1M x 256): the walk is bound by its chain of dependent LDS / memory round trips and by how
+// many walks share a SIMD, not by instruction issue.  Kept because the ISA is the one a reader expects.
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ KEntry uni(const KEntry &e) { return KEntry{uni(e.key), uni(e.node)}; }
+
+// The candidate queue of a walk: entries [0, nl) in LDS, the rest in global memory (see the file header).
+struct HybQ {
+  KEntry *lds;
+  KEntry *glb;
+  int nl;
+  __device__ __forceinline__ KEntry get(int i) const { return uni(i < nl ? lds[i] : glb[i - nl]); }
+  __device__ __forceinline__ void set(int i, const KEntry &e) const {
+    if (i < nl) lds[i] = e;
+    else glb[i - nl] = e;
+  }
+};
+template <bool MINQ>
+__device__ inline void hq_add(const HybQ &q, int &n, KEntry x) {  // PriorityQueue.offer -> siftUpUsingComparator
+  int k = n++;
+  while (k > 0) {
+    const int parent = (k - 1) >> 1;
+    const KEntry e = q.get(parent);
+    if (!k_before<MINQ>(x.key, e.key)) break;
+    q.set(k, e);
+    k = parent;
+  }
+  q.set(k, x);
+}
+template <bool MINQ>
+__device__ inline KEntry hq_poll(const HybQ &q, int &n) {  // PriorityQueue.poll -> siftDownUsingComparator
+  const KEntry result = q.get(0);
+  const int s = --n;
+  if (s > 0) {
+    const KEntry x = q.get(s);
+    int k = 0;
+    const int half = s >> 1;
+    while (k < half) {
+      int child = 2 * k + 1;
+      KEntry c = q.get(child);
+      const int right = child + 1;
+      if (right < s) {
+        const KEntry r = q.get(right);
+        if (k_before<MINQ>(r.key, c.key)) {  // comparator(c, r) > 0
+          c = r;
+          child = right;
+        }
+      }
+      if (!k_before<MINQ>(c.key, x.key)) break;  // comparator(x, c) <= 0
+      q.set(k, c);
+      k = child;
+    }
+    q.set(k, x);
+  }
+  return result;
+}
+// plain LDS heap (the result queue): the same two operations without the LDS / global split
+template <bool MINQ>
+__device__ inline void kq_add(KEntry *q, int &n, KEntry x) {
+  int k = n++;
+  while (k > 0) {
+    const int parent = (k - 1) >> 1;
+    const KEntry e = uni(q[parent]);
+    if (!k_before<MINQ>(x.key, e.key)) break;
+    q[k] = e;
+    k = parent;
+  }
+  q[k] = x;
+}
+template <bool MINQ>
+__device__ inline KEntry kq_poll(KEntry *q, int &n) {
+  const KEntry result = uni(q[0]);
+  const int s = --n;
+  if (s > 0) {
+    const KEntry x = uni(q[s]);
+    int k = 0;
+    const int half = s >> 1;
+    while (k < half) {
+      int child = 2 * k + 1;
+      KEntry c = uni(q[child]);
+      const int right = child + 1;
+      if (right < s) {
+        const KEntry r = uni(q[right]);
+        if (k_before<MINQ>(r.key, c.key)) {
+          c = r;
+          child = right;
+        }
+      }
+      if (!k_before<MINQ>(c.key, x.key)) break;
+      q[k] = c;
+      k = child;
+    }
+    q[k] = x;
+  }
+  return result;
+}
+
 // distance from the fixed-order sum (see file header)
 __host__ __device__ inline float finish_distance(int metric, float s) {
   return metric == HNSW_METRIC_L2 ? sqrtf(s) : 1.0f - s;
@@ -171,15 +292,16 @@ struct SearchArgs {
   const int64_t *ids;         // or NULL
   const int32_t *qlist;       // queries of this launch (spill re-run) or NULL = blockIdx
   uint32_t *visited;          // [slots][vwords]
-  HEntry *gc, *gw;            // global queues (GLOBALQ): [slots][CCAP_GLOBAL], [slots][MAX_EF + 1]
+  KEntry *gc;                 // candidate-queue tails: [slots][gcap]
   float *out_dist;            // [nq][k]
   int64_t *out_ids;
   int32_t *out_counts;
   int32_t *spill;             // [nq] set when the LDS candidate queue overflowed
-  unsigned long long *stats;  // [0] distance evaluations, [1] expansions, [2] largest candidate queue, [3..9] queries by the tier that fits them
+  unsigned long long *stats;  // [0] distance evaluations, [1] expansions, [2] largest candidate queue, [3] admissions
   int64_t vwords;
   int32_t dpad, chunks, m, m0, metric, k, ef, max_level;
-  int32_t ccap_lds;           // candidate-queue entries allowed in LDS (<= CCAP_LDS; smaller only for tests)
+  int32_t ccap_lds;           // candidate-queue entries in LDS (the top of the heap)
+  int32_t gcap;               // ... and in global memory, per slot
   uint32_t entry;
 };
 
@@ -225,18 +347,17 @@ __device__ __forceinline__ void wave_distances(const Args &a, const float (&qv)[
   }
 }
 
-template <int CH, bool GLOBALQ>
+template <int CH>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
-  extern __shared__ HEntry dyn_s[];  // !GLOBALQ: result queue [ef + 1], then candidate queue [ccap_lds]
-  HEntry *wq_s = dyn_s, *cq_s = dyn_s + a.ef + 1;
+  extern __shared__ KEntry dyn_s[];  // result queue [ef + 1], then the top of the candidate queue [ccap_lds]
+  KEntry *wq = dyn_s;
   __shared__ uint32_t ul[64];
   __shared__ float ud[64];
   const int lane = threadIdx.x;
   const int slot = blockIdx.x;
   const int qi = a.qlist ? a.qlist[slot] : slot;
-  HEntry *cq = GLOBALQ ? a.gc + (size_t)slot * CCAP_GLOBAL : cq_s;
-  HEntry *wq = GLOBALQ ? a.gw + (size_t)slot * (MAX_EF + 1) : wq_s;
-  const int ccap = GLOBALQ ? CCAP_GLOBAL : a.ccap_lds;
+  const HybQ cq{dyn_s + a.ef + 1, a.gc + (size_t)slot * a.gcap, a.ccap_lds};
+  const int ccap = a.ccap_lds + a.gcap;
   uint32_t *vis = a.visited + (size_t)slot * a.vwords;
 
   float qv[CH][8];
@@ -250,7 +371,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
       for (int e = 0; e < 8; ++e) qv[c][e] = (float)v[e];
     }
   }
-  unsigned long long n_dist = 0, n_exp = 0;
+  unsigned long long n_dist = 0, n_exp = 0, n_adm = 0;
 
   // ---- bestEntryPointUntilLayer (HnswIndex.java:447-475) ----
   uint32_t cur = a.entry;
@@ -259,7 +380,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
     __syncthreads();
     wave_distances<CH>(a, qv, ul, ud, 1, lane);
     __syncthreads();
-    float cur_dist = ud[0];
+    float cur_dist = uni(ud[0]);
     n_dist += 1;
     for (int level = a.max_level; level > 0; --level) {
       bool changed = true;
@@ -282,10 +403,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
           n_dist += cnt;
           // `for nn in list: if (d < curDist) take it`: the running strict minimum, in list order
           for (int i = 0; i < cnt; ++i) {
-            const float t = ud[i];
+            const float t = uni(ud[i]);
             if (t < cur_dist) {
               cur_dist = t;
-              cur = ul[i];
+              cur = uni(ul[i]);
               changed = true;
             }
           }
@@ -305,20 +426,21 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
   int cn = 0, wn = 0, peak = 1;
   bool overflow = false;
   {
-    const HEntry e0{ud[0], cur};
-    pq_add<true>(cq, cn, e0);
-    pq_add<false>(wq, wn, e0);
+    const KEntry e0{dist_key(uni(ud[0])), cur};
+    hq_add<true>(cq, cn, e0);
+    wq[0] = e0;  // (an offer into an empty queue)
+    wn = 1;
     if (lane == 0) atomicOr(&vis[cur >> 5], 1u << (cur & 31));
   }
-  float lower = wq[0].dist;
+  float lower = key_dist(uni(wq[0].key));
   __syncthreads();
   while (cn > 0) {
-    const HEntry cand = cq[0];
-    if (cand.dist > lower) break;
-    (void)pq_poll<true>(cq, cn);
+    const KEntry cand = cq.get(0);
+    if (key_dist(cand.key) > lower) break;
+    (void)hq_poll<true>(cq, cn);
     n_exp += 1;
     const uint32_t *row = a.adj0 + (size_t)cand.node * (a.m0 + 1);
-    const int cnt = (int)row[0];
+    const int cnt = (int)uni(row[0]);
     uint32_t nn = 0;
     bool fresh = false;
     if (lane < cnt) {
@@ -334,18 +456,25 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
       wave_distances<CH>(a, qv, ul, ud, nu, lane);
       __syncthreads();
       n_dist += nu;
-      for (int i = 0; i < nu; ++i) {
-        const HEntry e{ud[i], ul[i]};
-        if (wn < ef || e.dist < wq[0].dist) {
+      // `lower` never rises once the result queue is full, so a neighbour that fails `d < lower` now fails it when its turn
+      // comes: one ballot drops those, and the admission loop -- list order kept -- only visits the rest
+      unsigned long long live = __ballot(lane < nu && (wn < ef || ud[lane < nu ? lane : 0] < lower));
+      while (live) {
+        const int i = __builtin_ctzll(live);
+        live &= live - 1;
+        const float d = uni(ud[i]);
+        if (wn < ef || d < lower) {  // (lower is the result queue's head at all times)
+          n_adm += 1;
           if (cn >= ccap) {
             overflow = true;
             break;
           }
-          pq_add<true>(cq, cn, e);
+          const KEntry e{dist_key(d), uni(ul[i])};
+          hq_add<true>(cq, cn, e);
           peak = cn > peak ? cn : peak;
-          pq_add<false>(wq, wn, e);
-          if (wn > ef) (void)pq_poll<false>(wq, wn);
-          lower = wq[0].dist;
+          kq_add<false>(wq, wn, e);
+          if (wn > ef) (void)kq_poll<false>(wq, wn);
+          lower = key_dist(uni(wq[0].key));
         }
       }
     }
@@ -355,12 +484,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
   if (lane == 0) {
     atomicAdd(&a.stats[0], n_dist);
     atomicAdd(&a.stats[1], n_exp);
+    atomicAdd(&a.stats[3], n_adm);
     atomicMax(&a.stats[2], (unsigned long long)(overflow ? ccap + 1 : peak));  // largest candidate queue of the launch
-    if (!overflow) {  // (a query finishes exactly once) which LDS tier would have been enough for it
-      int t = 0;
-      while (t < N_CCAP_TIERS && peak > CCAP_TIERS[t]) ++t;
-      atomicAdd(&a.stats[3 + t], 1ull);
-    }
   }
   if (overflow) {
     if (lane == 0) a.spill[qi] = 1;
@@ -370,9 +495,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
   const int found = wn;
   const int m = found < a.k ? found : a.k;
   for (int pos = found - 1; pos >= 0; --pos) {
-    const HEntry e = pq_poll<false>(wq, wn);
+    const KEntry e = kq_poll<false>(wq, wn);
     if (pos < m && lane == 0) {
-      a.out_dist[(size_t)qi * a.k + pos] = e.dist;
+      a.out_dist[(size_t)qi * a.k + pos] = key_dist(e.key);
       a.out_ids[(size_t)qi * a.k + pos] = a.ids ? a.ids[e.node] : (int64_t)e.node;
     }
   }
@@ -763,12 +888,11 @@ struct hnsw_index {
   Buf x, adj0, upper_slot, upper_base, upper_adj, ids;
   bool has_ids = false;
   // scratch
-  Buf q_in, q, visited, gc, gw, o_dist, o_ids, o_cnt, spill, stats, qlist;
+  Buf q_in, q, visited, gc, o_dist, o_ids, o_cnt, spill, stats, qlist;
   hipEvent_t ev[2] = {nullptr, nullptr};
   int64_t last_dist = 0, last_exp = 0;
   int32_t last_spilled = 0;
-  int64_t last_peak = 0;
-  int8_t tier_hint[MAX_EF + 1] = {};  // [beam]: 1 + the LDS tier at which the next search of that beam width starts (0 = none yet)
+  int64_t last_peak = 0, last_adm = 0;
   float last_ms = 0;
   int64_t build_rounds = 0, build_truncated = 0, build_prunes = 0, build_dropped = 0;  // hnsw_index_build_insert_gpu
   ~hnsw_index() {
@@ -1109,27 +1233,21 @@ int create_index(int32_t device, int32_t metric, int64_t n, int32_t d, const flo
 }
 
 template <int CH>
-int launch_search(bool globalq, int blocks, const SearchArgs &a, hipStream_t st) {
-  // LDS per wave = the two queues
-  const size_t lds = globalq ? 0 : (size_t)(a.ef + 1 + a.ccap_lds) * sizeof(HEntry);
-  if (globalq) {
-    hipLaunchKernelGGL((hnsw_search_kernel<CH, true>), dim3(blocks), dim3(64), lds, st, a);
-  } else {
-    if (lds > 60 * 1024) HTRY(hipFuncSetAttribute((const void *)hnsw_search_kernel<CH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((hnsw_search_kernel<CH, false>), dim3(blocks), dim3(64), lds, st, a);
-  }
+int launch_search(int blocks, const SearchArgs &a, hipStream_t st) {
+  const size_t lds = (size_t)(a.ef + 1 + a.ccap_lds) * sizeof(HEntry);
+  hipLaunchKernelGGL((hnsw_search_kernel<CH>), dim3(blocks), dim3(64), lds, st, a);
   return HNSW_OK;
 }
-int launch_search_any(int chunks, bool globalq, int blocks, const SearchArgs &a, hipStream_t st) {
+int launch_search_any(int chunks, int blocks, const SearchArgs &a, hipStream_t st) {
   switch (chunks) {
-    case 1: return launch_search<1>(globalq, blocks, a, st);
-    case 2: return launch_search<2>(globalq, blocks, a, st);
-    case 3: return launch_search<3>(globalq, blocks, a, st);
-    case 4: return launch_search<4>(globalq, blocks, a, st);
-    case 5: return launch_search<5>(globalq, blocks, a, st);
-    case 6: return launch_search<6>(globalq, blocks, a, st);
-    case 7: return launch_search<7>(globalq, blocks, a, st);
-    default: return launch_search<8>(globalq, blocks, a, st);
+    case 1: return launch_search<1>(blocks, a, st);
+    case 2: return launch_search<2>(blocks, a, st);
+    case 3: return launch_search<3>(blocks, a, st);
+    case 4: return launch_search<4>(blocks, a, st);
+    case 5: return launch_search<5>(blocks, a, st);
+    case 6: return launch_search<6>(blocks, a, st);
+    case 7: return launch_search<7>(blocks, a, st);
+    default: return launch_search<8>(blocks, a, st);
   }
 }
 
@@ -1544,7 +1662,6 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   a.ids = ix->has_ids ? ix->ids.as<int64_t>() : nullptr;
   a.visited = ix->visited.as<uint32_t>();
   a.gc = nullptr;
-  a.gw = nullptr;
   a.out_dist = ix->o_dist.as<float>();
   a.out_ids = ix->o_ids.as<int64_t>();
   a.out_counts = ix->o_cnt.as<int32_t>();
@@ -1560,49 +1677,29 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   a.ef = beam;
   a.max_level = ix->max_level;
   a.entry = (uint32_t)ix->entry;
-  // every admission enters the candidate queue and stale ones stay: it reaches 2-3x the beam on clustered data and
-  // far more on structureless data (i.i.d. Gaussians), hence the tiers
-  constexpr int N_TIERS = (int)(sizeof(CCAP_TIERS) / sizeof(CCAP_TIERS[0]));
-  int tier_cap[N_TIERS + 1];
-  int n_lds_tiers = 0;
-  bool skip_mid = false;
-  if (const char *e = getenv("HNSW_DEBUG_CCAP")) {  // tests: shrink tier 1; a negative value keeps the big LDS tier, a positive one goes straight to global memory
+  // Every admission enters the candidate queue and stale ones stay: it reaches 2-3x the beam on clustered data and far more
+  // on structureless data (i.i.d. Gaussians).  Its top is in LDS -- as much as WALK_LDS_BYTES leaves beside the result queue
+  // -- and the rest in global memory: CCAP_FIRST entries per query in the first pass, CCAP_GLOBAL for the queries that
+  // outgrow that (pass 2, at most 256 at a time).
+  int lds_n = std::max(64, std::min(CCAP_LDS, (int)((WALK_LDS_BYTES - (size_t)(beam + 1) * sizeof(HEntry)) / sizeof(HEntry))));
+  if ((size_t)(beam + 1) * sizeof(HEntry) + 64 * sizeof(HEntry) > (size_t)WALK_LDS_BYTES) lds_n = 64;
+  int gcap_first = CCAP_FIRST;
+  if (const char *e = getenv("HNSW_DEBUG_CCAP")) {  // tests: v > 0: v entries in LDS and v in the first pass's global part (so queries spill into pass 2); v < 0: |v| in LDS, the usual global part
     const int v = atoi(e);
-    tier_cap[n_lds_tiers++] = std::min(CCAP_LDS, std::max(1, v < 0 ? -v : v));
-    if (v < 0) tier_cap[n_lds_tiers++] = CCAP_LDS_BIG;
-    skip_mid = true;
-  } else {
-    // start at the smallest tier that held nine tenths of the queries of the last search with this beam width; without
-    // history, at the first tier of at least 2.5 beams (the queue reaches 2-3x the beam on clustered data).  Small tiers
-    // matter for small beams: at ef = 100 the 2048-entry tier's 16 KB allowed 9 walks per CU, 512 entries allow 32.
-    int t0 = 0;
-    if (ix->tier_hint[beam] > 0) t0 = ix->tier_hint[beam] - 1;
-    else
-      while (t0 < N_TIERS - 1 && CCAP_TIERS[t0] < beam * 5 / 2) ++t0;
-    for (int t = t0; t < N_TIERS; ++t) tier_cap[n_lds_tiers++] = CCAP_TIERS[t];
+    lds_n = std::min(CCAP_LDS, std::max(1, v < 0 ? -v : v));
+    if (v > 0) gcap_first = v;
   }
-  (void)skip_mid;
 
   HTRY(hipEventRecord(ix->ev[0], st));
   std::vector<int32_t> redo, spill((size_t)nq);
-  // tier index n_lds_tiers = queues in global memory
-  for (int tier = 0; tier <= n_lds_tiers; ++tier) {
-    const bool globalq = tier == n_lds_tiers;
-    const bool first = tier == 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool first = pass == 0;
     if (!first && redo.empty()) break;
     const int64_t todo = first ? nq : (int64_t)redo.size();
-    // queries per launch: visited bitmaps, and no more waves than the LDS lets run at once (a launch of more would
-    // only queue; smaller launches keep the bitmap memset small)
-    int64_t batch = per_launch;
-    if (globalq) {
-      batch = std::min<int64_t>(batch, 256);
-      HTRY(ix->gc.reserve((size_t)std::min<int64_t>(batch, todo) * CCAP_GLOBAL * sizeof(HEntry)));
-      HTRY(ix->gw.reserve((size_t)std::min<int64_t>(batch, todo) * (MAX_EF + 1) * sizeof(HEntry)));
-    } else if (!first) {
-      const size_t lds = (size_t)(beam + 1 + tier_cap[tier]) * sizeof(HEntry) + 1024;
-      batch = std::min<int64_t>(batch, 256 * std::max<int64_t>(1, (int64_t)(160 * 1024 / lds)));
-    }
+    const int gcap = first ? gcap_first : CCAP_GLOBAL;
+    int64_t batch = std::min<int64_t>(per_launch, first ? (int64_t)1 << 16 : 256);
     batch = std::min<int64_t>(batch, todo);
+    HTRY(ix->gc.reserve((size_t)batch * gcap * sizeof(HEntry)));
     if (!first) {
       HTRY(ix->qlist.reserve(redo.size() * 4));
       HTRY(hipMemcpyAsync(ix->qlist.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
@@ -1622,10 +1719,10 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
         b.q = ix->q.as<_Float16>();
         b.qlist = ix->qlist.as<int32_t>() + r0;
       }
-      b.gc = ix->gc.as<HEntry>();
-      b.gw = ix->gw.as<HEntry>();
-      b.ccap_lds = globalq ? CCAP_LDS : tier_cap[tier];
-      int rc = launch_search_any(a.chunks, globalq, (int)m, b, st);
+      b.gc = ix->gc.as<KEntry>();
+      b.ccap_lds = lds_n;
+      b.gcap = gcap;
+      int rc = launch_search_any(a.chunks, (int)m, b, st);
       if (rc) return rc;
       HTRY(hipGetLastError());
     }
@@ -1653,15 +1750,7 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   ix->last_dist = (int64_t)stats[0];
   ix->last_exp = (int64_t)stats[1];
   ix->last_peak = (int64_t)stats[2];
-  if (!getenv("HNSW_DEBUG_CCAP")) {
-    unsigned long long cum = 0;
-    int t = 0;
-    for (; t < N_CCAP_TIERS - 1; ++t) {
-      cum += stats[3 + t];
-      if (cum * 10 >= (unsigned long long)nq * 9) break;
-    }
-    ix->tier_hint[beam] = (int8_t)(t + 1);
-  }
+  ix->last_adm = (int64_t)stats[3];
   (void)hipEventElapsedTime(&ix->last_ms, ix->ev[0], ix->ev[1]);
   return HNSW_OK;
 } ABI_CATCH
@@ -1673,6 +1762,13 @@ int hnsw_last_stats(const hnsw_index_t *ix, int64_t *distance_evals, int64_t *ex
   if (expansions) *expansions = ix->last_exp;
   if (spilled_queries) *spilled_queries = ix->last_spilled;
   if (kernel_ms) *kernel_ms = ix->last_ms;
+  return HNSW_OK;
+} ABI_CATCH
+
+int hnsw_last_walk_counters(const hnsw_index_t *ix, int64_t *admissions, int64_t *largest_candidate_queue) try {
+  if (!ix) return fail(HNSW_EINVAL, "NULL index");
+  if (admissions) *admissions = ix->last_adm;
+  if (largest_candidate_queue) *largest_candidate_queue = ix->last_peak;
   return HNSW_OK;
 } ABI_CATCH
 

@@ -37,6 +37,7 @@ PROTOS = {
     "hnsw_index_get_vectors": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "hnsw_index_destroy": (C.c_int, [C.c_void_p]),
     "hnsw_search": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hnsw_last_walk_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "hnsw_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
 }
 
@@ -170,7 +171,10 @@ class Hnsw:
         lib = _lib()
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int32(), C.c_float()
         _check(lib, lib.hnsw_last_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        return dict(distance_evals=a.value, expansions=b.value, spilled_queries=c.value, kernel_ms=d.value)
+        e, f = C.c_int64(), C.c_int64()
+        _check(lib, lib.hnsw_last_walk_counters(self._h, C.byref(e), C.byref(f)))
+        return dict(distance_evals=a.value, expansions=b.value, spilled_queries=c.value, kernel_ms=d.value, admissions=e.value,
+                    largest_candidate_queue=f.value)
 
     def close(self):
         if self._h:

@@ -80,12 +80,14 @@ def main():
                                    f"{a.queries} queries, k={k}, ef={ef}"},
             "ms_per_batch": wall * 1e3, "kernel_ms": st["kernel_ms"], "recall_at_k": recall,
             "distance_evals_per_query": st["distance_evals"] / a.queries, "expansions_per_query": st["expansions"] / a.queries,
+            "admissions_per_query": st["admissions"] / a.queries, "largest_candidate_queue": st["largest_candidate_queue"],
             "distance_evals_per_sec": st["distance_evals"] / (st["kernel_ms"] * 1e-3),
             "roofline": {"bound": "hbm", "achieved": st["distance_evals"] * row_bytes / (st["kernel_ms"] * 1e-3) / 1e9, "peak": 8000.0,
                          "unit": "GB/s", "frac": st["distance_evals"] * row_bytes / (st["kernel_ms"] * 1e-3) / 8e12,
                          "note": "random 512-B row gathers; latency-bound walk"},
             "cpu_baseline": cpu,
-            "spilled_queries": st["spilled_queries"], "build_s": build_s, "build": a.build, "build_threads": a.threads}), flush=True)
+            "spilled_queries": st["spilled_queries"], "build_s": build_s, "build": a.build, "build_threads": a.threads,
+            "device_build_counters": dict(zip(("rounds", "unseen_additions", "queue_prunes", "dropped_candidates"), ix.build_stats())) if a.build == "gpu" else None}), flush=True)
     ix.close(); bf.close()
 
 
