@@ -153,6 +153,8 @@ def main():
                     help="N > 1 (or --exercise-exchange): tweet-hash shards (the deployment: no data moves before the top-k) or the "
                          "cluster-id-range shards north_star names (every batch moves the scanned lists' top-M prefixes to the GPU "
                          "their tweets hash to: exact, and 17x the exchange bytes -- DESIGN.md section 4)")
+    ap.add_argument("--quality-topical-tweets", type=int, default=1_000_000,
+                    help="size of the topic-mixture corpus of the second quality field (recall_at_400_quality_topical); 0 = skip")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight: consecutive steps alternate between this many HIP streams")
     ap.add_argument("--rotate", type=int, default=8,
                     help="distinct prepared query batches the timed loop rotates through (each its own 1024*N synthetic users): 8 "
@@ -671,6 +673,17 @@ def main():
             tot += min(len(found), len(truth)) if found else len(truth)
         recall_quality = hit / max(tot, 1)
 
+    # ---- the same quality measure where the data has the structure the algorithm relies on: a topic-mixture corpus (tweets and
+    #      users draw 90 % of their clusters from their topic's 64), host-generated at --quality-topical-tweets, the operator on
+    #      the GPU vs the exact full cosine by scipy over every tweet's full embedding (tools/quality_topics.py) -----------------
+    recall_topical = None
+    if world == 1 and co is None and args.quality_topical_tweets > 0 and args.alg == "cosine":
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import quality_topics
+        r = quality_topics.run(pkg, args.quality_topical_tweets, 32, 2000, 400, alg)
+        recall_topical = {"value": r["recall_at_k_quality"], "min": r["min"], "max": r["max"], "tweets": r["tweets"], "queries": r["queries"],
+                          "topics": r["n_topics"], "corpus": "corpus.make_corpus(n_topics=2000): 90 % of a tweet's / user's clusters from its topic's 64"}
+
     # ---- CPU baseline: the C restatement of the Scala path on the host cores, bounded sample ---
     cpu = None
     if not args.no_cpu_baseline and (co is not None or world == 1):
@@ -744,6 +757,7 @@ def main():
         "postings_per_sec": postings_per_step * args.steps / elapsed,
         "recall_at_400_parity": recall_parity,
         "recall_at_400_quality": recall_quality,
+        "recall_at_400_quality_topical": recall_topical,
         "quality_checked_queries": (min(args.quality_queries, nq) if recall_quality is not None else 0),
         "parity_checked_queries": n_check,
         "fallback_units": n_fallback_units,

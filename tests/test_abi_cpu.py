@@ -85,7 +85,7 @@ def test_jni_glue_compiles_against_the_minimal_jni_header():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     jni = os.path.join(root, "the-algorithm_amd", "jni")
     want = {
-        "simclusters_ann_jni.c": ("com_twitter_simclustersann_gpu_SannJni", ("indexBuild", "indexDestroy", "hostAlloc", "hostFree", "getTweetCandidates0", "heavyRank0")),
+        "simclusters_ann_jni.c": ("com_twitter_simclustersann_gpu_SannJni", ("indexBuild", "indexDestroy", "hostAlloc", "hostFree", "getTweetCandidates0", "heavyRank0", "batcherCreate", "batcherDestroy", "request0")),
         "representation_scorer_jni.c": ("com_twitter_representationscorer_gpu_RsxJni", ("storeBuild", "storeDestroy", "pairScores", "listScores")),
         "ann_jni.c": ("com_twitter_ann_gpu_AnnJni", ("denseIndexBuild", "denseIndexDestroy", "denseSearch", "hnswIndexBuildInsert",
                                                      "hnswIndexLoadDirectory", "hnswIndexDestroy", "hnswSearch")),

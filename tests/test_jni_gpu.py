@@ -32,6 +32,22 @@ def test_sann_through_the_glue_equals_the_oracle(pkg, oracle):
                                                co.list_offsets, co.tweet_ids, co.scores)
         assert cnt[q] == len(o_ids) and msz[q] == o_msz
         assert np.array_equal(ids[q, :cnt[q]], o_ids) and np.array_equal(sc[q, :cnt[q]].view(np.int64), o_sc.view(np.int64))
+    # one request at a time through the native micro-batching queue (what a Finagle worker thread calls): the same answers
+    mb, msg, _ = e.call(SANN, "batcherCreate", C.c_int64, C.c_int64(h), 0, 0, 200, 2)
+    assert msg is None and mb != 0
+    for q in range(nq):
+        r_ids, r_sc, r_cm = np.zeros(k, np.int64), np.zeros(k), np.zeros(2, np.int32)
+        rc, msg, _ = e.call(SANN, "request0", C.c_int32, C.c_int64(mb), C.c_int64(co.now_ms), e.array(cids[offs[q]:offs[q + 1]].astype(np.int32)),
+                            e.array(scs[offs[q]:offs[q + 1]].astype(np.float64)), C.c_int64(0), C.c_uint8(0), e.buffer(cbuf), e.array(r_ids),
+                            e.array(r_sc), e.array(r_cm))
+        assert rc == 0 and msg is None
+        assert r_cm[0] == cnt[q] and r_cm[1] == msz[q]
+        assert np.array_equal(r_ids[:cnt[q]], ids[q, :cnt[q]]) and np.array_equal(r_sc[:cnt[q]].view(np.int64), sc[q, :cnt[q]].view(np.int64))
+    rc, msg, _ = e.call(SANN, "request0", C.c_int32, C.c_int64(mb), C.c_int64(co.now_ms), e.array(cids[:3].astype(np.int32)),
+                        e.array(scs[:3].astype(np.float64)), C.c_int64(0), C.c_uint8(0), e.buffer(cbuf), e.array(np.zeros(5, np.int64)),
+                        e.array(np.zeros(5)), e.array(np.zeros(2, np.int32)))
+    assert rc != 0 and "shorter" in msg
+    e.call(SANN, "batcherDestroy", None, C.c_int64(mb))
     # pinned buffers through the glue
     b, msg, _ = e.call(SANN, "hostAlloc", C.c_void_p, C.c_int64(4096))
     assert b and msg is None

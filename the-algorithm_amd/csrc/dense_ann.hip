@@ -908,13 +908,17 @@ int dann_index_get_vectors(const dann_index_t *ix, int64_t i0, int64_t n, float 
   if (!ix || !out || i0 < 0 || n < 0 || i0 + n > ix->n) return fail(DANN_EINVAL, "range outside the index");
   if (n == 0) return DANN_OK;
   DTRY(hipSetDevice(ix->device));
+  // in slabs of <= 2^28 elements: a launch must stay below 2^32 work-items (hnsw_index_get_vectors found out at 50M x 256)
+  const int64_t slab = std::max<int64_t>(1, ((int64_t)1 << 28) / ix->d);
   Buf tmp;
-  DTRY(tmp.reserve((size_t)n * ix->d * sizeof(float)));
-  int64_t e = n * ix->d;
-  hipLaunchKernelGGL(unfrag_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, 0, ix->xf.as<_Float16>(), ix->S, ix->d,
-                     i0, n, tmp.as<float>());
-  DTRY(hipGetLastError());
-  DTRY(hipMemcpy(out, tmp.p, (size_t)e * sizeof(float), hipMemcpyDeviceToHost));
+  DTRY(tmp.reserve((size_t)std::min(slab, n) * ix->d * sizeof(float)));
+  for (int64_t r0 = 0; r0 < n; r0 += slab) {
+    const int64_t m = std::min(slab, n - r0), e = m * ix->d;
+    hipLaunchKernelGGL(unfrag_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, 0, ix->xf.as<_Float16>(), ix->S, ix->d,
+                       i0 + r0, m, tmp.as<float>());
+    DTRY(hipGetLastError());
+    DTRY(hipMemcpy(out + (size_t)r0 * ix->d, tmp.p, (size_t)e * sizeof(float), hipMemcpyDeviceToHost));
+  }
   return DANN_OK;
 } ABI_CATCH
 

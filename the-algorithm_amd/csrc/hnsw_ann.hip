@@ -1582,13 +1582,18 @@ int hnsw_index_get_vectors(const hnsw_index_t *ix, int64_t i0, int64_t n, float 
   if (!ix || !out || i0 < 0 || n < 0 || i0 + n > ix->n) return fail(HNSW_EINVAL, "range outside the index");
   if (n == 0) return HNSW_OK;
   HTRY(hipSetDevice(ix->device));
+  // in slabs: a launch stays far below 2^32 work-items (50M x 256 elements in ONE launch is 1.28e10 -- the grid wrapped and
+  // most of the buffer came back unwritten: profiles/r03_hnsw_bench_50M_*) and the staging buffer below 1 GiB
+  const int64_t slab = std::max<int64_t>(1, ((int64_t)1 << 28) / ix->d);  // rows per launch: <= 2^28 elements
   Buf tmp;
-  HTRY(tmp.reserve((size_t)n * ix->d * 4));
-  const int64_t e = n * ix->d;
-  hipLaunchKernelGGL(hnsw_rows_to_f32, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, 0, ix->x.as<_Float16>(), i0, n, ix->d,
-                     ix->dpad, tmp.as<float>());
-  HTRY(hipGetLastError());
-  HTRY(hipMemcpy(out, tmp.p, (size_t)e * 4, hipMemcpyDeviceToHost));
+  HTRY(tmp.reserve((size_t)std::min(slab, n) * ix->d * 4));
+  for (int64_t r0 = 0; r0 < n; r0 += slab) {
+    const int64_t m = std::min(slab, n - r0), e = m * ix->d;
+    hipLaunchKernelGGL(hnsw_rows_to_f32, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, 0, ix->x.as<_Float16>(), i0 + r0, m, ix->d,
+                       ix->dpad, tmp.as<float>());
+    HTRY(hipGetLastError());
+    HTRY(hipMemcpy(out + (size_t)r0 * ix->d, tmp.p, (size_t)e * 4, hipMemcpyDeviceToHost));
+  }
   return HNSW_OK;
 } ABI_CATCH
 
@@ -1634,8 +1639,10 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   }
   HTRY(hipSetDevice(ix->device));
   const int64_t vwords = (ix->n + 31) / 32;
-  // concurrent queries per launch: bounded by the visited bitmaps (<= 2 GiB of them)
-  int64_t per_launch = std::min<int64_t>(nq, std::max<int64_t>(64, (int64_t)(2ull << 30) / (vwords * 4)));
+  // concurrent queries per launch: bounded by the visited bitmaps -- n bits per query, up to 48 GiB of the 288 (at 50M
+  // vectors a bitmap is 6.25 MB; the 2 GiB this was capped at until round 3 let 343 walks run at a time, 1.3 per CU,
+  // and a 4096-query batch took twelve launches: profiles/r03_hnsw_bench_50M_*)
+  int64_t per_launch = std::min<int64_t>(nq, std::max<int64_t>(64, (int64_t)(48ull << 30) / (vwords * 4)));
   per_launch = std::min<int64_t>(per_launch, 1 << 16);
   HTRY(ix->q_in.reserve((size_t)nq * ix->d * 4));
   HTRY(ix->q.reserve((size_t)nq * ix->dpad * sizeof(_Float16)));

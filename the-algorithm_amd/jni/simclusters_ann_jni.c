@@ -22,6 +22,7 @@
 #endif
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/simclusters_ann.h"
 
@@ -212,5 +213,102 @@ JNIEXPORT jint JNICALL Java_com_twitter_simclustersann_gpu_SannJni_heavyRank0(
 #undef CAP
 #undef BUF
   if (rc != SANN_OK) throw_runtime(env, sann_last_error());
+  return rc;
+}
+
+/* ---- the native micro-batching queue: what a Finagle worker thread calls, once per request -------------------------------
+ * long batcherCreate(long index, int variant, int maxBatch, int maxWaitUs, int nDispatchers)   (0 = the library's defaults)
+ * void batcherDestroy(long batcher)
+ * int  request0(long batcher, long nowMs, int[] clusterIds, double[] scores, long sourceTweetId, boolean hasSourceTweet,
+ *               ByteBuffer config /+ one sann_config_t, 40 bytes +/, long[] outIds, double[] outScores, int[] outCountAndMapSize)
+ * = ApproximateCosineSimilarity.apply for ONE request (ApproximateCosineSimilarity.scala:26-36), blocking the calling thread for
+ * the batching window + one batch's GPU time, as the reference's call blocks it for its CPU time
+ * (SimClustersANNCandidateSource.scala:77-94).  The Java arrays are copied in and out (GetArrayRegion / SetArrayRegion, no
+ * pinning across the wait); outIds / outScores must hold min(maxNumResults, 1000) entries; outCountAndMapSize = {count, map size}. */
+JNIEXPORT jlong JNICALL Java_com_twitter_simclustersann_gpu_SannJni_batcherCreate(JNIEnv *env, jclass cls, jlong index, jint variant,
+                                                                                   jint maxBatch, jint maxWaitUs, jint nDispatchers) {
+  (void)cls;
+  sann_batcher_options_t o = {variant, maxBatch, maxWaitUs, nDispatchers};
+  sann_batcher_t *b = NULL;
+  if (sann_batcher_create((sann_index_t *)(intptr_t)index, &o, &b) != SANN_OK) {
+    throw_runtime(env, sann_last_error());
+    return 0;
+  }
+  return (jlong)(intptr_t)b;
+}
+JNIEXPORT void JNICALL Java_com_twitter_simclustersann_gpu_SannJni_batcherDestroy(JNIEnv *env, jclass cls, jlong batcher) {
+  (void)env;
+  (void)cls;
+  sann_batcher_destroy((sann_batcher_t *)(intptr_t)batcher);
+}
+JNIEXPORT jint JNICALL Java_com_twitter_simclustersann_gpu_SannJni_request0(JNIEnv *env, jclass cls, jlong batcher, jlong nowMs,
+                                                                             jintArray clusterIds, jdoubleArray scores, jlong sourceTweetId,
+                                                                             jboolean hasSourceTweet, jobject config, jlongArray outIds,
+                                                                             jdoubleArray outScores, jintArray outCountAndMapSize) {
+  (void)cls;
+  enum { MAX_EMB = 4096, MAX_OUT = 1000 };
+  int32_t c[MAX_EMB];
+  double s[MAX_EMB];
+  int64_t ids[MAX_OUT];
+  double sc[MAX_OUT];
+  if (!batcher || !clusterIds || !scores || !config || !outIds || !outScores || !outCountAndMapSize) {
+    throw_runtime(env, "a required argument is null");
+    return SANN_EINVAL;
+  }
+  const jsize n = (*env)->GetArrayLength(env, clusterIds);
+  if ((*env)->GetArrayLength(env, scores) != n || n > MAX_EMB) {
+    throw_runtime(env, "clusterIds / scores differ in length or hold more than 4096 entries");
+    return SANN_EINVAL;
+  }
+  if ((*env)->GetDirectBufferCapacity(env, config) < (jlong)sizeof(sann_config_t) || (*env)->GetArrayLength(env, outCountAndMapSize) < 2) {
+    throw_runtime(env, "config must hold one sann_config_t and outCountAndMapSize two ints");
+    return SANN_EINVAL;
+  }
+  const sann_config_t *cfg = (const sann_config_t *)(*env)->GetDirectBufferAddress(env, config);
+  int32_t cap = cfg->max_num_results < MAX_OUT ? cfg->max_num_results : MAX_OUT;
+  if (cap < 0) cap = 0;
+  if ((*env)->GetArrayLength(env, outIds) < cap || (*env)->GetArrayLength(env, outScores) < cap) {
+    throw_runtime(env, "outIds / outScores are shorter than min(maxNumResults, 1000)");
+    return SANN_EINVAL;
+  }
+  { /* copy in: pinned only for the copy, never across the wait below */
+    void *pc = (*env)->GetPrimitiveArrayCritical(env, clusterIds, NULL);
+    void *ps = (*env)->GetPrimitiveArrayCritical(env, scores, NULL);
+    if (pc && ps) {
+      memcpy(c, pc, (size_t)n * 4);
+      memcpy(s, ps, (size_t)n * 8);
+    }
+    if (ps) (*env)->ReleasePrimitiveArrayCritical(env, scores, ps, JNI_ABORT);
+    if (pc) (*env)->ReleasePrimitiveArrayCritical(env, clusterIds, pc, JNI_ABORT);
+    if (!pc || !ps) {
+      throw_runtime(env, "could not pin the embedding arrays");
+      return SANN_ENOMEM;
+    }
+  }
+  int32_t cm[2] = {0, 0};
+  const int rc = sann_batcher_get_tweet_candidates((sann_batcher_t *)(intptr_t)batcher, nowMs, n, c, s, sourceTweetId, hasSourceTweet ? 1 : 0,
+                                                   cfg, cap > 0 ? cap : 1, ids, sc, &cm[0], &cm[1]);
+  if (rc != SANN_OK) {
+    throw_runtime(env, sann_last_error());
+    return rc;
+  }
+  { /* copy out */
+    void *pi = (*env)->GetPrimitiveArrayCritical(env, outIds, NULL);
+    void *ps = (*env)->GetPrimitiveArrayCritical(env, outScores, NULL);
+    void *pm = (*env)->GetPrimitiveArrayCritical(env, outCountAndMapSize, NULL);
+    const int ok = pi && ps && pm;
+    if (ok) {
+      memcpy(pi, ids, (size_t)cm[0] * 8);
+      memcpy(ps, sc, (size_t)cm[0] * 8);
+      memcpy(pm, cm, 8);
+    }
+    if (pm) (*env)->ReleasePrimitiveArrayCritical(env, outCountAndMapSize, pm, 0);
+    if (ps) (*env)->ReleasePrimitiveArrayCritical(env, outScores, ps, 0);
+    if (pi) (*env)->ReleasePrimitiveArrayCritical(env, outIds, pi, 0);
+    if (!ok) {
+      throw_runtime(env, "could not pin the output arrays");
+      return SANN_ENOMEM;
+    }
+  }
   return rc;
 }
