@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Build gate for every HIP source of csrc/: no kernel may spill a vector register.
 
-ROCm 7.2's hipcc was seen placing VGPR spill stores in FRONT of the exec-mask restore of a join block (the ISA excerpt is in
-tools/check_unit_kernel_resources.py: `scratch_store_dword` of a per-lane value, then `s_or_b64 exec, exec, ...`), so lanes that
+ROCm 7.2's hipcc was seen (round 2, unit_fast_kernel at 64 registers; the listing was not kept) placing VGPR spill stores in FRONT of
+the exec-mask restore of a join block -- `scratch_store_dword` of a per-lane value, then `s_or_b64 exec, exec, ...` -- so lanes that
 were masked off inside the branch reload garbage later -- a kernel that spills VGPRs inside divergent control flow is not merely
 slower, it can be wrong.  Scratch that comes from a per-thread ARRAY (the synthetic-corpus generators keep small arrays) is not a
 spill and is allowed; `VGPRs Spill` above zero is not.  SGPR spills go to VGPR lanes and are reported, not refused.
