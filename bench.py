@@ -169,12 +169,12 @@ def main():
                          "and out (N = 1 only; -1 = as many as --steps, 0 = skip)")
     ap.add_argument("--e2e-threads", type=int, default=4, help="concurrent callers of the end-to-end leg (the reference's callers are Finagle worker threads)")
     ap.add_argument("--e2e-query-sets", type=int, default=4, help="distinct query batches the end-to-end leg rotates through")
-    ap.add_argument("--mb-threads", type=int, default=8, help="caller threads of the micro-batched leg (0 = skip)")
-    ap.add_argument("--mb-window", type=int, default=128, help="single requests each caller thread keeps in flight (outstanding Futures)")
-    ap.add_argument("--mb-requests", type=int, default=262144, help="single requests of the micro-batched leg, all threads together")
+    ap.add_argument("--mb-threads", type=int, default=4, help="caller threads of the micro-batched leg (0 = skip)")
+    ap.add_argument("--mb-window", type=int, default=2048, help="single requests each caller thread keeps in flight (outstanding Futures)")
+    ap.add_argument("--mb-requests", type=int, default=786432, help="single requests of the micro-batched leg, all threads together")
     ap.add_argument("--mb-batch", type=int, default=1024, help="max_batch of the micro-batching queue in that leg")
-    ap.add_argument("--mb-wait-us", type=int, default=200, help="max_wait_us of the micro-batching queue in that leg")
-    ap.add_argument("--mb-dispatchers", type=int, default=3)
+    ap.add_argument("--mb-wait-us", type=int, default=300, help="max_wait_us of the micro-batching queue in that leg")
+    ap.add_argument("--mb-dispatchers", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cpu_count, 16))")
     args = ap.parse_args()
     if args.workload != "sann":
@@ -573,7 +573,7 @@ def main():
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)]
             cfg_e = cfg.to_c()
             r3 = (ctypes.c_double * 3)()
-            n_nat = max(n_e2e, 40)
+            n_nat = max(10 * n_e2e, 400)  # (0.1 s of calls: the pipeline's ramp-up -- the first few calls -- is not what is measured)
             for n_calls in (2 * n_thr, n_nat):
                 rc = ld.e2e_load_run(index.handle, n_thr, n_calls, nq, n_sets, a_o, a_c, a_s, ctypes.byref(cfg_e), now_ms, r3)
                 assert rc == 0, lib.sann_last_error()
