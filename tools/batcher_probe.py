@@ -25,7 +25,7 @@ o, c, s = np.ascontiguousarray(offs, np.int64), np.ascontiguousarray(cids, np.in
 res = (ctypes.c_double * 6)()
 for threads, window, batch, wait, disp in [(int(x) for x in a.split(":")) for a in (sys.argv[2:] or ["8:64:512:200:3", "8:128:1024:200:3"])]:
     mb = pkg.MicroBatcher(index, max_batch=batch, max_wait_us=wait, n_dispatchers=disp)
-    for n_req in (2 * window, max(4 * window, 131072 // threads)):
+    for n_req in (2 * window, max(4 * window, int(os.environ.get("PROBE_REQUESTS", 131072)) // threads)):  # warm-up, then the measured run (requests per thread)
         rc = load.batcher_load_run(mb._h, threads, window, n_req, 1024, o.ctypes.data, c.ctypes.data, s.ctypes.data, ctypes.byref(cfg_c), pkg.corpus.NOW_MS, res)
         assert rc == 0, lib.sann_last_error()
     st = mb.stats()

@@ -14,7 +14,7 @@ import __graft_entry__ as ge  # noqa: E402
 pkg = ge.load_package()
 lib = pkg.load_library()
 tweets = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
-n_sets, nq = 8, 1024
+n_sets, nq = 8, int(os.environ.get("PROBE_NQ", 1024))  # queries per call
 o_all, c_all, s_all = pkg.corpus.make_queries(nq * n_sets)
 keep = []
 for i in range(n_sets):
