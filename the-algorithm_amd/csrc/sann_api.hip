@@ -1525,6 +1525,10 @@ static bool trace_on() {
   return t;
 }
 static double trace_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static int zero_copy_mode() {  // SANN_ZERO_COPY: 0 never, 1 (default) for a call that finds the pipeline empty, 2 always
+  static const int m = [] { const char *e = getenv("SANN_ZERO_COPY"); return e ? atoi(e) : 1; }();
+  return m;
+}
 static bool memcpy_when_busy() {  // SANN_COPY_MEMCPY=1: the runtime's copies instead of the copy kernel while the pipeline is full
   static const bool t = [] { const char *e = getenv("SANN_COPY_MEMCPY"); return e && e[0] == '1'; }();
   return t;
@@ -1545,6 +1549,7 @@ struct EngineJob {
   sann_batch *b = nullptr;
   int slot = 0;
   int stage = 0;  // 1 kernels enqueued, 2 copies enqueued
+  bool zero_copy = false;  // the merge kernel writes the answer straight into the caller's pinned arrays
   int rc = SANN_OK;
   std::string msg;
   std::mutex m;
@@ -1566,6 +1571,10 @@ struct sann_engine {
   void finish_job(EngineJob *j) {
     std::string keep = g_err;
     {  // the batch object goes back to the pool (a device error may have left it in an unknown state: dropped then)
+      if (j->b && j->zero_copy) {  // (the caller's arrays are the caller's again)
+        j->b->bound_ids = j->b->bound_scores = j->b->bound_counts = j->b->bound_map_sizes = nullptr;
+        j->b->bound_nq = j->b->bound_stride = 0;
+      }
       bool pooled = false;
       if (j->b && (j->rc == SANN_OK || j->rc == SANN_EINVAL || j->rc == SANN_ELIMIT)) {
         std::lock_guard<std::mutex> lk(ix->pool_mu);
@@ -1589,7 +1598,7 @@ struct sann_engine {
   }
 
   // reset + kernels of a job on stream `slot`, its unit kernel behind `prev`'s
-  void submit(EngineJob *j, int slot, sann_batch *prev) {
+  void submit(EngineJob *j, int slot, sann_batch *prev, bool pipeline_empty) {
     j->slot = slot;
     sann_batch *b = nullptr;
     {
@@ -1612,6 +1621,37 @@ struct sann_engine {
     hipStream_t st = streams[slot];
     j->rc = batch_reset(b, st, j->now_ms, j->nq, j->emb_offsets, j->emb_cluster_ids, j->emb_scores, j->source_tweet_ids,
                         j->has_source_tweet, j->configs, j->n_configs, j->scan_offsets, j->scan_cluster_ids, j->now_ms_q);
+    // Zero copy (round 3), for a SMALL call (<= 256 queries) that finds the pipeline EMPTY -- the latency case, a single request
+    // or a thin micro-batch: when the caller's four arrays are pinned (sann_host_alloc) and laid out at the batch's own stride,
+    // the merge kernel is pointed at them and writes every query's rows home as it finishes them (one query: 0.107 against
+    // 0.118 ms per call).  Not for the throughput case: a merge kernel writing over PCIe holds its workgroups' slots until the
+    // stores have crossed, and with calls in flight the pipeline loses more than the copy kernel cost (1024 queries: 0.30
+    // against 0.27-0.28 ms per call with four or eight callers; a lone 1024-query caller would gain 10 %, 0.43 against 0.47,
+    // but a burst of callers starts as a lone caller).  SANN_ZERO_COPY=0 turns it off, =2 forces it for every call (measurements).
+    j->zero_copy = false;
+    if (j->rc == SANN_OK && (zero_copy_mode() == 2 || (zero_copy_mode() == 1 && pipeline_empty && b->nq <= 256)) && b->nq > 0 && j->out_stride == b->stride && j->out_ids && j->out_scores && j->out_counts &&
+        j->out_map_sizes) {
+      void *d[4] = {nullptr, nullptr, nullptr, nullptr};
+      const void *h[4] = {j->out_ids, j->out_scores, j->out_counts, j->out_map_sizes};
+      bool pinned = true;
+      for (int i = 0; i < 4 && pinned; i++) {
+        hipPointerAttribute_t at;
+        pinned = hipPointerGetAttributes(&at, h[i]) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr;
+        if (pinned) d[i] = at.devicePointer;
+      }
+      (void)hipGetLastError();
+      if (pinned) {
+        b->bound_ids = d[0];
+        b->bound_scores = d[1];
+        b->bound_counts = d[2];
+        b->bound_map_sizes = d[3];
+        b->bound_chunk_q = 0;
+        b->bound_chunk_pitch = 0;
+        b->bound_nq = b->nq;
+        b->bound_stride = b->stride;
+        j->zero_copy = true;
+      }
+    }
     if (j->rc == SANN_OK) j->rc = sann_batch_run_after(b, st, prev, 0);
     if (j->rc == SANN_OK) j->stage = 1;
   }
@@ -1635,7 +1675,7 @@ struct sann_engine {
         for (auto it = inflight.rbegin(); it != inflight.rend(); ++it)
           if ((*it)->stage == 1 && (*it)->b) { prev = (*it)->b; break; }
         const double t_s = trace_on() ? trace_now() : 0.0;
-        submit(j, next_slot, prev);
+        submit(j, next_slot, prev, inflight.empty());
         if (trace_on()) { g_trace_us[0] += trace_now() - t_s; g_trace_calls++; }
         if (j->rc != SANN_OK) finish_job(j);
         else {
@@ -1663,7 +1703,7 @@ struct sann_engine {
         const double t_f = trace_on() ? trace_now() : 0.0;
         k1->rc = sann_batch_finish(k1->b, st);
         const double t_r = trace_on() ? trace_now() : 0.0;
-        if (k1->rc == SANN_OK)
+        if (k1->rc == SANN_OK && !k1->zero_copy)
           k1->rc = results_impl(k1->b, st, k1->out_ids, k1->out_scores, k1->out_stride, k1->out_counts, k1->out_map_sizes, false,
                                 /* by_kernel = */ !memcpy_when_busy() || inflight.size() < (size_t)kStreams);
         if (trace_on()) { g_trace_us[2] += t_r - t_f; g_trace_us[1] += trace_now() - t_r; }
