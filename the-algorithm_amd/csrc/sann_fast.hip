@@ -217,11 +217,11 @@ __global__ __launch_bounds__(WG, (WG < 256 ? 2 : NORMS ? (U <= 8 ? 5 : 2) : U <=
   // The survivor list, the radix histogram / lane maxima and the match list of the duplicate phase are first touched
   // after the Bloom filter is dead (the barrier that ends phase 2 lies between): they live in its memory when it is
   // large enough.
-  constexpr bool ALIAS = BLOOM_ALLOC >= SCAP + (WG > 256 ? WG / 2 : 128);
-  constexpr int M_OFF = SCAP + (WG > 256 ? WG / 2 : 128);  // in 8-byte words: behind the survivor list and the histogram / lane maxima ([WG] words)
+  constexpr bool ALIAS = BLOOM_ALLOC >= SCAP + 128;
+  constexpr int M_OFF = SCAP + 128;  // in 8-byte words: behind the survivor list and the histogram
   constexpr bool ALIAS_M = ALIAS && BLOOM_ALLOC >= M_OFF + 5 * MCAP;
   __shared__ unsigned long long s_ent_own[ALIAS ? 1 : SCAP];
-  __shared__ unsigned s_hist_own[ALIAS ? 1 : (WG > 256 ? WG : 256)];
+  __shared__ unsigned s_hist_own[ALIAS ? 1 : 256];
   __shared__ long long s_Mid_own[ALIAS_M ? 1 : MCAP];
   __shared__ double s_Msc_own[ALIAS_M ? 1 : MCAP], s_Mdot_own[ALIAS_M ? 1 : MCAP], s_Mnsq_own[ALIAS_M ? 1 : MCAP];
   __shared__ int s_Mseq_own[ALIAS_M ? 1 : MCAP], s_Mrole_own[ALIAS_M ? 1 : MCAP];
@@ -1124,9 +1124,7 @@ hipError_t launch_unit_fast(const IndexView &ix, const BatchView &b, const FastP
     case 1024: return launch_one<256, 4>(ix, b, fp, stream);
     case 1536: return launch_one<256, 6>(ix, b, fp, stream);
     case 2048: return launch_one<256, 8>(ix, b, fp, stream);
-    case 3072:
-      if (getenv("SANN_GEOM512")) return launch_one<512, 6>(ix, b, fp, stream);
-      return launch_one<256, 12>(ix, b, fp, stream);
+    case 3072: return launch_one<256, 12>(ix, b, fp, stream);
     case 4096: return launch_one<256, 16>(ix, b, fp, stream);
     default: return hipErrorInvalidValue;
   }
