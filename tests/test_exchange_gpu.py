@@ -73,3 +73,30 @@ def test_exchange_argument_errors(pkg):
     assert lib.sann_comm_create(0, 2, 2, C.create_string_buffer(128), C.byref(C.c_void_p())) == 1  # rank out of range
     assert lib.sann_exchange_to_owners(None, None, None, None, 8) == 1
     assert lib.sann_comm_unique_id(None) == 1
+
+
+@pytest.mark.parametrize("sharding", ["tweet-hash", "cluster-range"])
+def test_bench_sharded_modes_with_one_rank(sharding):
+    """bench.py's N > 1 code paths with a single rank (--exercise-exchange): process group, the library's RCCL communicator,
+    the exchange(s) and the owner's merge; the answers must equal the unsharded index's.  Runs in a child process (it
+    initialises torch.distributed and redirects its stdout)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--exercise-exchange", "--sharding", sharding, "--tweets", "2000000",
+                        "--queries-per-gpu", "128", "--steps", "3", "--warmup", "1", "--rotate", "2", "--no-cpu-baseline", "--e2e-steps", "0"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    if sharding == "cluster-range":
+        assert line["sharded_equals_unsharded"] is True
+    else:  # one tweet-hash shard IS the whole index: what went through the exchange and the owner's merge is held to the oracle
+        assert line["recall_at_400_parity"] == 1.0 and line["parity_checked_queries"] >= 16
+    assert line["config"]["sharding"] == (sharding if sharding == "cluster-range" else "none") and line["value"] > 0  # (one rank: "none")
+    assert line["config"].get("queries_not_proven_by_cut_lists", 0) == 0
