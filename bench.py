@@ -169,12 +169,12 @@ def main():
                          "and out (N = 1 only; -1 = as many as --steps, 0 = skip)")
     ap.add_argument("--e2e-threads", type=int, default=4, help="concurrent callers of the end-to-end leg (the reference's callers are Finagle worker threads)")
     ap.add_argument("--e2e-query-sets", type=int, default=4, help="distinct query batches the end-to-end leg rotates through")
-    ap.add_argument("--mb-threads", type=int, default=2, help="caller threads of the micro-batched leg (0 = skip)")
-    ap.add_argument("--mb-window", type=int, default=4096, help="single requests each caller thread keeps in flight (outstanding Futures)")
-    ap.add_argument("--mb-requests", type=int, default=1048576, help="single requests of the micro-batched leg, all threads together")
+    ap.add_argument("--mb-threads", type=int, default=8, help="caller threads of the micro-batched leg (0 = skip)")
+    ap.add_argument("--mb-window", type=int, default=128, help="single requests each caller thread keeps in flight (outstanding Futures)")
+    ap.add_argument("--mb-requests", type=int, default=524288, help="single requests of the micro-batched leg, all threads together")
     ap.add_argument("--mb-batch", type=int, default=1024, help="max_batch of the micro-batching queue in that leg")
-    ap.add_argument("--mb-wait-us", type=int, default=300, help="max_wait_us of the micro-batching queue in that leg")
-    ap.add_argument("--mb-dispatchers", type=int, default=8)
+    ap.add_argument("--mb-wait-us", type=int, default=200, help="max_wait_us of the micro-batching queue in that leg")
+    ap.add_argument("--mb-dispatchers", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cpu_count, 16))")
     args = ap.parse_args()
     if args.workload != "sann":

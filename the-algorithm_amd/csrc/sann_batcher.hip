@@ -62,11 +62,27 @@ struct Request {
   std::string message;
 };
 
+// The embeddings of a batch's requests, back to back.  Plain buffers, not std::vector: a submitter RESERVES its stretch under the
+// queue's lock and copies into it after letting the lock go (`pending` counts the copies still running; the dispatcher waits
+// for zero before it reads), so growing must never move the buffer under a writer -- a batch that would outgrow its buffer is
+// closed instead, and only an EMPTY batch grows.
+struct EmbBuf {
+  std::unique_ptr<int32_t[]> cids;
+  std::unique_ptr<double[]> scores;
+  size_t size = 0, cap = 0;
+  void reserve_empty(size_t n) {  // (size == 0: nobody holds a pointer into the old buffers)
+    if (n <= cap) return;
+    cids.reset(new int32_t[n]);
+    scores.reset(new double[n]);
+    cap = n;
+  }
+};
+
 struct Batch {
   std::shared_ptr<BatchSync> sync{new BatchSync()};
   std::vector<int64_t> emb_offsets{0};
-  std::vector<int32_t> cids;
-  std::vector<double> scores;
+  EmbBuf emb;
+  std::atomic<int> pending{0};
   std::vector<int64_t> src, now;
   std::vector<uint8_t> has_src;
   std::vector<sann_config_t> cfgs;
@@ -75,7 +91,8 @@ struct Batch {
   int kmax = 1;
   void clear() {
     emb_offsets.assign(1, 0);
-    cids.clear(); scores.clear(); src.clear(); now.clear(); has_src.clear(); cfgs.clear(); reqs.clear();
+    emb.size = 0;
+    src.clear(); now.clear(); has_src.clear(); cfgs.clear(); reqs.clear();
     kmax = 1;
     sync.reset(new BatchSync());
   }
@@ -105,8 +122,15 @@ struct sann_batcher {
   std::unique_ptr<Batch> open;                 // accepting requests (never null)
   std::deque<std::unique_ptr<Batch>> ready;    // closed, waiting for a dispatcher
   std::vector<std::unique_ptr<Batch>> spare;   // recycled
-  std::mutex tk_mu;  // the ticket table has a lock of its own: collecting answers does not hold up submissions
-  std::unordered_map<int64_t, std::shared_ptr<Request>> tickets;
+  // the ticket table has locks of its own (collecting answers does not hold up submissions), sixteen of them: a ticket's
+  // shard is its low bits, so callers that submit and collect at a million requests a second rarely meet
+  static constexpr int TK_SHARDS = 16;
+  struct TicketShard {
+    std::mutex mu;
+    std::unordered_map<int64_t, std::shared_ptr<Request>> map;
+  };
+  TicketShard tk[TK_SHARDS];
+  TicketShard &shard_of(int64_t ticket) { return tk[(size_t)ticket & (TK_SHARDS - 1)]; }
   std::vector<std::thread> workers;
   std::atomic<int64_t> next_ticket{1};
   bool stop = false;
@@ -120,9 +144,8 @@ struct sann_batcher {
     else {
       open.reset(new Batch());
       open->reqs.reserve((size_t)opt.max_batch);
-      open->cids.reserve((size_t)opt.max_batch * 64);
-      open->scores.reserve((size_t)opt.max_batch * 64);
     }
+    open->emb.reserve_empty((size_t)opt.max_batch * 64);
     cv_work.notify_one();
   }
 
@@ -143,8 +166,8 @@ struct sann_batcher {
       sc = (double *)((char *)ob.p + row * (size_t)nq);
       cnt = (int32_t *)((char *)ob.p + 2 * row * (size_t)nq);
       msz = cnt + nq;
-      rc = sann_candidates_pooled(ix, opt.variant, bt.now[0], bt.now.data(), nq, bt.emb_offsets.data(), bt.cids.data(),
-                                  bt.scores.data(), bt.src.data(), bt.has_src.data(), bt.cfgs.data(), nq, nullptr, nullptr, ids, sc,
+      rc = sann_candidates_pooled(ix, opt.variant, bt.now[0], bt.now.data(), nq, bt.emb_offsets.data(), bt.emb.cids.get(),
+                                  bt.emb.scores.get(), bt.src.data(), bt.has_src.data(), bt.cfgs.data(), nq, nullptr, nullptr, ids, sc,
                                   stride, cnt, msz);
       if (rc != SANN_OK) msg = sann_last_error();
     }
@@ -206,6 +229,7 @@ struct sann_batcher {
       n_batches++;
       max_batch_seen = std::max<int64_t>(max_batch_seen, (int64_t)bt->reqs.size());
       lk.unlock();
+      while (bt->pending.load(std::memory_order_acquire) != 0) std::this_thread::yield();  // (submitters still copying their embeddings in)
       run_batch(*bt, ob);
       bt->clear();
       lk.lock();
@@ -232,6 +256,7 @@ int sann_batcher_create(sann_index_t *index, const sann_batcher_options_t *optio
   b->ix = index;
   b->opt = o;
   b->open.reset(new Batch());
+  b->open->emb.reserve_empty((size_t)o.max_batch * 64);
   for (int i = 0; i < o.n_dispatchers; i++) b->workers.emplace_back([p = b.get()] { p->worker(); });
   *out = b.release();
   return SANN_OK;
@@ -249,7 +274,7 @@ int sann_submit(sann_batcher_t *b, int64_t now_ms, int32_t n_embedding, const in
   }
   const int k = config->max_num_results < 1000 ? (config->max_num_results < 0 ? 0 : config->max_num_results) : 1000;
   if (out_capacity < k || (k > 0 && (!out_ids || !out_scores))) return fail(SANN_EINVAL, "out_capacity must hold min(maxNumResults, 1000) results");
-  std::shared_ptr<Request> r(new Request());
+  std::shared_ptr<Request> r = std::make_shared<Request>();
   r->ticket = b->next_ticket.fetch_add(1, std::memory_order_relaxed);
   r->out_cap = out_capacity;
   r->out_ids = out_ids;
@@ -257,21 +282,34 @@ int sann_submit(sann_batcher_t *b, int64_t now_ms, int32_t n_embedding, const in
   r->out_count = out_count;
   r->out_map_size = out_map_size;
   {
-    std::lock_guard<std::mutex> lk(b->tk_mu);
-    b->tickets.emplace(r->ticket, r);
+    auto &sh = b->shard_of(r->ticket);
+    std::lock_guard<std::mutex> lk(sh.mu);
+    sh.map.emplace(r->ticket, r);
   }
+  Batch *copy_to = nullptr;
+  size_t copy_at = 0;
   {
     std::lock_guard<std::mutex> lk(b->mu);
     if (b->stop) {
-      std::lock_guard<std::mutex> lk2(b->tk_mu);
-      b->tickets.erase(r->ticket);
+      auto &sh = b->shard_of(r->ticket);
+      std::lock_guard<std::mutex> lk2(sh.mu);
+      sh.map.erase(r->ticket);
       return fail(SANN_EINVAL, "the batcher is shutting down");
+    }
+    if (b->open->emb.size + (size_t)n_embedding > b->open->emb.cap) {  // would outgrow the buffer: close, and grow the (empty) next one
+      if (!b->open->reqs.empty()) {
+        b->n_full++;
+        b->close_open_locked();
+      }
+      b->open->emb.reserve_empty(std::max((size_t)n_embedding * 2, (size_t)b->opt.max_batch * 64));
     }
     Batch &bt = *b->open;
     if (bt.reqs.empty()) bt.deadline = Clock::now() + std::chrono::microseconds(b->opt.max_wait_us);
-    bt.cids.insert(bt.cids.end(), cluster_ids, cluster_ids + n_embedding);
-    bt.scores.insert(bt.scores.end(), scores, scores + n_embedding);
-    bt.emb_offsets.push_back((int64_t)bt.cids.size());
+    copy_to = &bt;
+    copy_at = bt.emb.size;
+    bt.emb.size += (size_t)n_embedding;
+    bt.pending.fetch_add(1, std::memory_order_relaxed);
+    bt.emb_offsets.push_back((int64_t)bt.emb.size);
     bt.src.push_back(has_source_tweet ? source_tweet_id : 0);
     bt.has_src.push_back(has_source_tweet ? 1 : 0);
     bt.now.push_back(now_ms);
@@ -288,16 +326,23 @@ int sann_submit(sann_batcher_t *b, int64_t now_ms, int32_t n_embedding, const in
       b->cv_work.notify_one();  // a dispatcher now has a deadline to sleep towards
     }
   }
+  // the embedding itself travels outside the lock, into the stretch reserved above
+  if (n_embedding > 0) {
+    memcpy(copy_to->emb.cids.get() + copy_at, cluster_ids, (size_t)n_embedding * sizeof(int32_t));
+    memcpy(copy_to->emb.scores.get() + copy_at, scores, (size_t)n_embedding * sizeof(double));
+  }
+  copy_to->pending.fetch_sub(1, std::memory_order_release);
   *ticket = r->ticket;
   return SANN_OK;
 } ABI_CATCH
 
 static int collect(sann_batcher *b, int64_t ticket, bool block, int32_t *done) {
   std::shared_ptr<Request> r;
+  auto &sh = b->shard_of(ticket);
   {
-    std::lock_guard<std::mutex> lk(b->tk_mu);
-    auto it = b->tickets.find(ticket);
-    if (it == b->tickets.end()) return fail(SANN_EINVAL, "unknown ticket (already collected?)");
+    std::lock_guard<std::mutex> lk(sh.mu);
+    auto it = sh.map.find(ticket);
+    if (it == sh.map.end()) return fail(SANN_EINVAL, "unknown ticket (already collected?)");
     r = it->second;
   }
   bool is_done;
@@ -309,8 +354,8 @@ static int collect(sann_batcher *b, int64_t ticket, bool block, int32_t *done) {
   if (done) *done = is_done ? 1 : 0;
   if (!is_done) return SANN_OK;
   {
-    std::lock_guard<std::mutex> lk(b->tk_mu);
-    if (b->tickets.erase(ticket) == 0) return fail(SANN_EINVAL, "unknown ticket (already collected?)");
+    std::lock_guard<std::mutex> lk(sh.mu);
+    if (sh.map.erase(ticket) == 0) return fail(SANN_EINVAL, "unknown ticket (already collected?)");
   }
   if (r->status != SANN_OK) return fail(r->status, r->message);
   return SANN_OK;
