@@ -112,3 +112,49 @@ def test_async_tickets_deadline_and_errors(pkg, oracle):
     o_ids, _, _ = _oracle_answer(oracle, co, reqs[1])
     assert int(out2[2][0]) == len(o_ids) and np.array_equal(out2[0][:len(o_ids)], o_ids)
     index.close()
+
+
+def test_embedding_buffer_limits_close_and_grow_the_open_batch(pkg, oracle):
+    """A batch's embeddings live in one buffer that submitters copy into after releasing the queue's lock, so it may never
+    move under them: a batch that would outgrow it is closed early, and a single request larger than the whole buffer makes
+    the next (empty) batch grow.  max_batch = 4 gives a 256-entry buffer: 30-entry embeddings close batches by size, not by
+    count; then a 700-entry embedding; then 24 threads race on the same tiny buffer.  Every answer is the oracle's."""
+    co = pkg.corpus.make_corpus(30_000, 900, seed=31, index_cap=600)
+    index = pkg.ClusterTweetIndex(co.cluster_ids, co.list_offsets, co.tweet_ids, co.scores)
+    mb = pkg.MicroBatcher(index, max_batch=4, max_wait_us=2000, n_dispatchers=2)
+    cfg = pkg.SimClustersANNConfig(maxNumResults=50, maxScanClusters=50)
+    try:
+        offs, cids, scs = pkg.corpus.make_queries(40, 900, seed=32, clusters_per_user=30)
+        reqs = [(cids[offs[q]:offs[q + 1]], scs[offs[q]:offs[q + 1]], cfg, None, co.now_ms) for q in range(40)]
+        big_c = np.arange(1, 701, dtype=np.int32)
+        big_s = np.random.default_rng(3).random(700) + 0.01
+        reqs.insert(17, (big_c, big_s, cfg, None, co.now_ms))
+        tickets = [mb.submit(r[0], r[1], r[2], now_ms=r[4]) for r in reqs]
+        for r, (t, out) in zip(reqs, tickets):
+            mb.wait(t)
+            o_ids, o_sc, o_m = _oracle_answer(oracle, co, r)
+            n = int(out[2][0])
+            assert n == len(o_ids) and int(out[3][0]) == o_m
+            assert np.array_equal(out[0][:n], o_ids) and np.array_equal(out[1][:n].view(np.int64), o_sc.view(np.int64))
+        got, errs = {}, []
+
+        def caller(t):
+            try:
+                for i in range(10):
+                    j = (t * 10 + i) % len(reqs)
+                    got[(t, i)] = (j, mb.get_tweet_candidates(reqs[j][0], reqs[j][1], cfg, now_ms=co.now_ms))
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        ths = [threading.Thread(target=caller, args=(t,)) for t in range(24)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert not errs, errs[0]
+        for (t, i), (j, ans) in got.items():
+            o_ids, o_sc, o_m = _oracle_answer(oracle, co, reqs[j])
+            assert np.array_equal(ans[0], o_ids) and np.array_equal(ans[1].view(np.int64), o_sc.view(np.int64)) and ans[2] == o_m
+    finally:
+        mb.close()
+        index.close()
