@@ -335,7 +335,10 @@ __device__ __forceinline__ void wave_distances(const Args &a, const float (&qv)[
               const float t = qv[c][e] - xe;
               acc = acc + t * t;
             } else {
-              acc = acc + qv[c][e] * xe;
+              // one v_fma_mix_f32 (the fp16 operand converted by the instruction) instead of cvt + mul + add -- and the same
+              // bits: both factors are fp16 values, so their product (22 significant bits) is exact in fp32 and the fused
+              // form rounds once exactly where `acc + q * x` rounds
+              acc = __builtin_fmaf(qv[c][e], xe, acc);
             }
           }
       }
@@ -575,7 +578,7 @@ __device__ __forceinline__ float group_row_distance(const BuildArgs &a, uint32_t
         const float t = fa - fb;
         acc = acc + t * t;
       } else {
-        acc = acc + fa * fb;
+        acc = __builtin_fmaf(fa, fb, acc);  // (exact product of two fp16 values: the same bits as acc + fa * fb, see wave_distances)
       }
     }
   }
