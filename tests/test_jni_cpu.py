@@ -118,3 +118,44 @@ def test_ann_glue_checks_capacities(pkg):
     assert r == 0 and "directory" in msg
     r, msg, _ = e.call(ANN, "hnswIndexLoadDirectory", C.c_int64, 0, 1, C.c_int64(4), 64, e.buffer(x), None, e.string("/nonexistent/index/dir"))
     assert r == 0 and msg  # the codec's message (hnsw_index_metadata could not be read)
+
+
+def test_java_binding_classes_match_the_compiled_glue():
+    """the-algorithm_amd/jni/java/**/*.java are the classes a JVM shim loads (no JDK here: they are not compiled).  Every `native`
+    method must have its JNI symbol in the glue with the same parameter list, type for type, and every JNIEXPORT function must be
+    declared by a class: the two sides cannot drift apart unnoticed."""
+    import glob
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jmap = {"int": "jint", "long": "jlong", "boolean": "jboolean", "double": "jdouble", "float": "jfloat", "void": "void",
+            "int[]": "jintArray", "long[]": "jlongArray", "double[]": "jdoubleArray", "float[]": "jfloatArray", "byte[]": "jbyteArray",
+            "ByteBuffer": "jobject", "String": "jstring"}
+    java = {}
+    for path in glob.glob(os.path.join(root, "the-algorithm_amd", "jni", "java", "**", "*.java"), recursive=True):
+        src = open(path).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        pkg = re.search(r"package\s+([\w.]+);", src).group(1)
+        cls = re.search(r"public final class (\w+)", src).group(1)
+        assert path.endswith(os.path.join(*pkg.split("."), cls + ".java")), "the file sits where its package says"
+        for m in re.finditer(r"public static native\s+([\w\[\]]+)\s+(\w+)\s*\(([^)]*)\)\s*;", src, re.S):
+            ret, name, args = m.groups()
+            types = [" ".join(a.split()[:-1]) for a in args.split(",") if a.strip()]
+            java["Java_" + pkg.replace(".", "_") + "_" + cls + "_" + name] = (jmap[ret], [jmap[t] for t in types])
+    glue = {}
+    for path in glob.glob(os.path.join(root, "the-algorithm_amd", "jni", "*.c")):
+        src = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+        for m in re.finditer(r"JNIEXPORT\s+(\w+)\s+JNICALL\s+(Java_\w+)\s*\(([^)]*)\)", src, re.S):
+            ret, name, args = m.groups()
+            types = [a.split()[0] for a in args.split(",")]
+            assert types[:2] == ["JNIEnv", "jclass"], name
+            glue[name] = (ret, types[2:])
+    assert len(java) >= 20 and set(java) == set(glue), sorted(set(java) ^ set(glue))
+    for name in java:
+        want = (java[name][0] if java[name][0] != "jobject" or glue[name][0] == "jobject" else "jobject", java[name][1])
+        assert glue[name] == want, (name, glue[name], java[name])
+    # and the symbols are really exported by the compiled glue (the harness links it)
+    lib = _jni.load()
+    for name in java:
+        assert hasattr(lib, name), name
