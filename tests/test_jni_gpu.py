@@ -117,6 +117,17 @@ def test_ann_through_the_glue_equals_the_direct_calls(pkg, tmp_path):
     ix = pkg.hnsw_ann.Hnsw.build(m, x, max_m=8, ef_construction=40, seed=5)
     r_ids, r_dist, r_cnt = ix.search(q, k, 50)
     assert np.array_equal(lab, r_ids) and np.array_equal(dist.view(np.int32), r_dist.view(np.int32))
+    # nThreads = 0: the deterministic device builder -- the graph the direct call builds, hence the same answers
+    hg, msg, _ = e.call(ANN, "hnswIndexBuildInsert", C.c_int64, 0, int(m), C.c_int64(n), d, e.buffer(x), None, 8, 40, C.c_int64(5), 0)
+    assert msg is None and hg
+    lab_g, dist_g, cnt_g = np.zeros_like(lab), np.zeros_like(dist), np.zeros_like(cnt)
+    _, msg, _ = e.call(ANN, "hnswSearch", None, C.c_int64(hg), nq, d, e.buffer(q), k, 50, e.buffer(dist_g), e.buffer(lab_g), e.buffer(cnt_g))
+    assert msg is None
+    ig = pkg.hnsw_ann.Hnsw.build(m, x, max_m=8, ef_construction=40, seed=5, gpu=True)
+    g_ids, g_dist, g_cnt = ig.search(q, k, 50)
+    ig.close()
+    assert np.array_equal(lab_g, g_ids) and np.array_equal(dist_g.view(np.int32), g_dist.view(np.int32)) and np.array_equal(cnt_g, g_cnt)
+    e.call(ANN, "hnswIndexDestroy", None, C.c_int64(hg))
     d_dir = str(tmp_path / "idx")
     pkg.ann_codec.save_directory(ix, 40, d_dir)
     ix.close()
