@@ -65,6 +65,8 @@ constexpr int CCAP_LDS = 1024;          // most candidate-queue entries kept in 
 constexpr int WALK_LDS_BYTES = 9 * 1024;  // dynamic LDS of a walk: result queue + candidate-queue top (16 walks per CU with the static 0.5 KB)
 constexpr int CCAP_FIRST = 8192;        // global part of the candidate queue, first pass (64 KB per query)
 constexpr int CCAP_GLOBAL = 1 << 17;    // ... of the re-run of a query that outgrew it
+constexpr int64_t VLOG_MIN_VWORDS = 1 << 18;  // bitmaps of at least 1 MB keep an undo log
+constexpr int VLOG_CAP = 1 << 16;       // visited nodes a walk remembers for cleaning up after itself (more: it wipes its whole bitmap)
 
 struct Buf {
   void *p = nullptr;
@@ -181,6 +183,22 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ KEntry uni(const KEntry &e) { return KEntry{uni(e.key), uni(e.node)}; }
 
+// The visited set is an n-bit bitmap per walk -- 6.25 MB at 50M vectors -- of which a walk sets a few thousand bits.  Wiping it
+// for every walk (a memset of every bitmap per search launch, or the builder's per-layer wipe) was 5 ms of a 4096-query batch
+// and a third of the build at 50M.  Instead every walk LOGS the nodes it marks (VLOG_CAP entries) and clears exactly those
+// words when it is done, so a bitmap that starts clean -- one memset when the buffer is allocated -- is clean again for the next
+// walk in the slot.  A walk that marks more than the log holds wipes its whole bitmap.  Used from 1 MB per bitmap (8M vectors)
+// up: below that the wipes are cheap and the log's stores are not (1M vectors: walk kernel 24.0 -> 25.0 ms with the log).
+__device__ __forceinline__ void visited_undo(uint32_t *vis, int64_t vwords, const uint32_t *vlog, int n_log, int lane) {
+  __threadfence_block();  // (the log was written by other lanes of this wave)
+  if (n_log <= VLOG_CAP) {
+    for (int i = lane; i < n_log; i += 64) vis[vlog[i] >> 5] = 0u;
+  } else {
+    for (int64_t w = lane; w < vwords; w += 64) vis[w] = 0u;
+  }
+  __threadfence_block();
+}
+
 // The candidate queue of a walk: entries [0, nl) in LDS, the rest in global memory (see the file header).
 struct HybQ {
   KEntry *lds;
@@ -291,7 +309,8 @@ struct SearchArgs {
   const uint32_t *upper_adj;  // [rows][m + 1]
   const int64_t *ids;         // or NULL
   const int32_t *qlist;       // queries of this launch (spill re-run) or NULL = blockIdx
-  uint32_t *visited;          // [slots][vwords]
+  uint32_t *visited;          // [slots][vwords]: clean when a walk starts, cleaned by the walk when it ends
+  uint32_t *vlog;             // [slots][VLOG_CAP]: the nodes the walk marked; NULL = small bitmaps: the host wipes them per launch
   KEntry *gc;                 // candidate-queue tails: [slots][gcap]
   float *out_dist;            // [nq][k]
   int64_t *out_ids;
@@ -362,6 +381,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
   const HybQ cq{dyn_s + a.ef + 1, a.gc + (size_t)slot * a.gcap, a.ccap_lds};
   const int ccap = a.ccap_lds + a.gcap;
   uint32_t *vis = a.visited + (size_t)slot * a.vwords;
+  uint32_t *vlog = a.vlog ? a.vlog + (size_t)slot * VLOG_CAP : nullptr;  // (uniform)
+  int n_log = 0;
 
   float qv[CH][8];
   {
@@ -433,7 +454,11 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
     hq_add<true>(cq, cn, e0);
     wq[0] = e0;  // (an offer into an empty queue)
     wn = 1;
-    if (lane == 0) atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+    if (lane == 0) {
+      atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+      if (vlog) vlog[0] = cur;
+    }
+    n_log = 1;
   }
   float lower = key_dist(uni(wq[0].key));
   __syncthreads();
@@ -453,7 +478,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
     }
     const unsigned long long mask = __ballot(fresh);
     const int nu = __popcll(mask);
-    if (fresh) ul[__popcll(mask & ((1ull << lane) - 1))] = nn;  // list order is kept
+    if (fresh) {
+      const int at = __popcll(mask & ((1ull << lane) - 1));
+      ul[at] = nn;  // list order is kept
+      if (vlog && n_log + at < VLOG_CAP) vlog[n_log + at] = nn;
+    }
+    n_log += nu;
     __syncthreads();
     if (nu > 0) {
       wave_distances<CH>(a, qv, ul, ud, nu, lane);
@@ -490,6 +520,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
     atomicAdd(&a.stats[3], n_adm);
     atomicMax(&a.stats[2], (unsigned long long)(overflow ? ccap + 1 : peak));  // largest candidate queue of the launch
   }
+  if (vlog) visited_undo(vis, a.vwords, vlog, n_log, lane);
   if (overflow) {
     if (lane == 0) a.spill[qi] = 1;
     return;
@@ -548,7 +579,8 @@ struct BuildArgs {
   const int32_t *levels;       // [n]
   const int64_t *pair_off;     // [n + 1] by order index: first key slot of an item ((layers wired) * m slots each)
   uint64_t *keys;              // the round's keys: phase A writes (unsorted buffer), phase B reads (sorted buffer)
-  uint32_t *visited;           // [round items][vwords]
+  uint32_t *visited;           // [round items][vwords]: clean between walks (visited_undo)
+  uint32_t *vlog;              // [round items][VLOG_CAP]; NULL = small bitmaps: a walk wipes its own before it starts
   unsigned long long *bstats;  // [0] additions a re-selection did not see, [1] candidate-queue prunes, [2] candidates dropped after a prune
   int64_t vwords;              // a multiple of 256
   int32_t dpad, metric, m, m0, efc, max_level;
@@ -614,6 +646,7 @@ __global__ __launch_bounds__(64) void hnsw_build_insert_kernel(BuildArgs a) {
   const uint32_t item = a.order[a.at + t];
   const int item_level = a.levels[item];
   uint32_t *vis = a.visited + (size_t)t * a.vwords;
+  uint32_t *vlog = a.vlog ? a.vlog + (size_t)t * VLOG_CAP : nullptr;  // (uniform)
   unsigned long long n_prune = 0, n_dropped = 0;
 
   float qv[CH][8];  // the item's own stored row is the query (distFnIndex, item to item)
@@ -664,8 +697,11 @@ __global__ __launch_bounds__(64) void hnsw_build_insert_kernel(BuildArgs a) {
   uint64_t *keys = a.keys + (a.pair_off[a.at + t] - a.pair_off[a.at]);
   for (int level = top; level >= 0; --level) {
     // ---- searchLayerForCandidates(item, cur, efConstruction, level) (:571-623, isUpdate = false): a fresh visited set ----
-    for (int64_t w = (int64_t)lane * 4; w < a.vwords; w += 256) *(uint4 *)(vis + w) = make_uint4(0u, 0u, 0u, 0u);
-    __threadfence_block();
+    int n_log = 0;  // (with a log the bitmap is clean: the previous walk of this slot undid its marks)
+    if (!vlog) {
+      for (int64_t w = (int64_t)lane * 4; w < a.vwords; w += 256) *(uint4 *)(vis + w) = make_uint4(0u, 0u, 0u, 0u);
+      __threadfence_block();
+    }
     if (lane == 0) ul[0] = cur;
     __syncthreads();
     wave_distances<CH>(a, qv, ul, ud, 1, lane);
@@ -675,7 +711,11 @@ __global__ __launch_bounds__(64) void hnsw_build_insert_kernel(BuildArgs a) {
       const HEntry e0{ud[0], cur};
       pq_add<true>(cq, cn, e0);
       pq_add<false>(wq, wn, e0);
-      if (lane == 0) atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+      if (lane == 0) {
+        atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+        if (vlog) vlog[0] = cur;
+      }
+      n_log = 1;
     }
     float lower = wq[0].dist;
     __syncthreads();
@@ -694,7 +734,12 @@ __global__ __launch_bounds__(64) void hnsw_build_insert_kernel(BuildArgs a) {
       }
       const unsigned long long mask = __ballot(fresh);
       const int nu = __popcll(mask);
-      if (fresh) ul[__popcll(mask & ((1ull << lane) - 1))] = nn;  // list order is kept
+      if (fresh) {
+        const int at = __popcll(mask & ((1ull << lane) - 1));
+        ul[at] = nn;  // list order is kept
+        if (vlog && n_log + at < VLOG_CAP) vlog[n_log + at] = nn;
+      }
+      n_log += nu;
       __syncthreads();
       if (nu > 0) {
         wave_distances<CH>(a, qv, ul, ud, nu, lane);
@@ -721,6 +766,7 @@ __global__ __launch_bounds__(64) void hnsw_build_insert_kernel(BuildArgs a) {
       }
       __syncthreads();
     }
+    if (vlog) visited_undo(vis, a.vwords, vlog, n_log, lane);
     // ---- selectNearestNeighboursByHeuristic(candidates, maxM) (:479-526); the item itself is never among them ----
     int nk = 0;
     if (wn <= a.m) {  // (:488-491) toListWithItem: the queue's ARRAY order
@@ -891,7 +937,8 @@ struct hnsw_index {
   Buf x, adj0, upper_slot, upper_base, upper_adj, ids;
   bool has_ids = false;
   // scratch
-  Buf q_in, q, visited, gc, o_dist, o_ids, o_cnt, spill, stats, qlist;
+  Buf q_in, q, visited, vlog, gc, o_dist, o_ids, o_cnt, spill, stats, qlist;
+  bool visited_dirty = true;  // the bitmaps must be wiped before the next search (fresh buffer, or a search that did not finish)
   hipEvent_t ev[2] = {nullptr, nullptr};
   int64_t last_dist = 0, last_exp = 0;
   int32_t last_spilled = 0;
@@ -1428,7 +1475,7 @@ static int build_insert_gpu_impl(int32_t device, int32_t metric, int64_t n, int3
       linked += m;
     }
     if (max_keys >= (int64_t)1 << 31) return fail(HNSW_EINVAL, "batch * max_m too large");
-    Buf d_order, d_levels, d_pair_off, d_keys, d_sorted, d_tmp, d_bstats, d_visited;
+    Buf d_order, d_levels, d_pair_off, d_keys, d_sorted, d_tmp, d_bstats, d_visited, d_vlog;
     HTRY(d_order.reserve((size_t)n * 4));
     HTRY(d_levels.reserve((size_t)n * 4));
     HTRY(d_pair_off.reserve(((size_t)n + 1) * 8));
@@ -1441,6 +1488,11 @@ static int build_insert_gpu_impl(int32_t device, int32_t metric, int64_t n, int3
     HTRY(hipMemset(d_bstats.p, 0, 4 * 8));
     const int64_t vwords = ((n + 31) / 32 + 255) / 256 * 256;
     HTRY(d_visited.reserve((size_t)max_items * vwords * 4));
+    const bool use_vlog = vwords >= VLOG_MIN_VWORDS || getenv("HNSW_DEBUG_VLOG") != nullptr;  // (the variable: tests force the log on small graphs)
+    if (use_vlog) {
+      HTRY(hipMemset(d_visited.p, 0, (size_t)max_items * vwords * 4));  // once: every walk cleans up after itself
+      HTRY(d_vlog.reserve((size_t)max_items * VLOG_CAP * 4));
+    }
     size_t tmp_bytes = 0;
     HTRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys.as<uint64_t>(), d_sorted.as<uint64_t>(), (int)max_keys, 0, 64, (hipStream_t)0));
     HTRY(d_tmp.reserve(tmp_bytes));
@@ -1454,6 +1506,7 @@ static int build_insert_gpu_impl(int32_t device, int32_t metric, int64_t n, int3
     a.levels = d_levels.as<int32_t>();
     a.pair_off = d_pair_off.as<int64_t>();
     a.visited = d_visited.as<uint32_t>();
+    a.vlog = use_vlog ? d_vlog.as<uint32_t>() : nullptr;
     a.bstats = d_bstats.as<unsigned long long>();
     a.vwords = vwords;
     a.dpad = ix->dpad;
@@ -1649,7 +1702,12 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   per_launch = std::min<int64_t>(per_launch, 1 << 16);
   HTRY(ix->q_in.reserve((size_t)nq * ix->d * 4));
   HTRY(ix->q.reserve((size_t)nq * ix->dpad * sizeof(_Float16)));
-  HTRY(ix->visited.reserve((size_t)per_launch * vwords * 4));
+  {
+    const void *before = ix->visited.p;
+    HTRY(ix->visited.reserve((size_t)per_launch * vwords * 4));
+    if (ix->visited.p != before) ix->visited_dirty = true;
+  }
+  const bool use_vlog = vwords >= VLOG_MIN_VWORDS || getenv("HNSW_DEBUG_VLOG") != nullptr;  // (the variable: tests force the log on small graphs)
   HTRY(ix->o_dist.reserve((size_t)nq * k * 4));
   HTRY(ix->o_ids.reserve((size_t)nq * k * 8));
   HTRY(ix->o_cnt.reserve((size_t)nq * 4));
@@ -1671,6 +1729,8 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   a.upper_adj = ix->upper_adj.as<uint32_t>();
   a.ids = ix->has_ids ? ix->ids.as<int64_t>() : nullptr;
   a.visited = ix->visited.as<uint32_t>();
+  if (use_vlog) HTRY(ix->vlog.reserve((size_t)per_launch * VLOG_CAP * 4));
+  a.vlog = use_vlog ? ix->vlog.as<uint32_t>() : nullptr;
   a.gc = nullptr;
   a.out_dist = ix->o_dist.as<float>();
   a.out_ids = ix->o_ids.as<int64_t>();
@@ -1700,6 +1760,9 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
     if (v > 0) gcap_first = v;
   }
 
+  // the visited bitmaps: wiped when the buffer is new (or a search was cut short); every walk leaves its own clean (visited_undo)
+  if (use_vlog && ix->visited_dirty) HTRY(hipMemsetAsync(ix->visited.p, 0, ix->visited.bytes, st));
+  ix->visited_dirty = true;  // (until this search has run to its end)
   HTRY(hipEventRecord(ix->ev[0], st));
   std::vector<int32_t> redo, spill((size_t)nq);
   for (int pass = 0; pass < 2; ++pass) {
@@ -1716,7 +1779,7 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
     }
     for (int64_t r0 = 0; r0 < todo; r0 += batch) {
       const int64_t m = std::min<int64_t>(batch, todo - r0);
-      HTRY(hipMemsetAsync(ix->visited.p, 0, (size_t)m * vwords * 4, st));
+      if (!use_vlog) HTRY(hipMemsetAsync(ix->visited.p, 0, (size_t)m * vwords * 4, st));
       SearchArgs b = a;
       if (first) {
         b.q = ix->q.as<_Float16>() + r0 * ix->dpad;
@@ -1757,6 +1820,7 @@ int hnsw_search(hnsw_index_t *ix, int32_t nq, const float *queries, int32_t k, i
   HTRY(hipMemcpyAsync(out_ids, ix->o_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
   HTRY(hipMemcpyAsync(out_counts, ix->o_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
   HTRY(hipStreamSynchronize(st));
+  ix->visited_dirty = !use_vlog;
   ix->last_dist = (int64_t)stats[0];
   ix->last_exp = (int64_t)stats[1];
   ix->last_peak = (int64_t)stats[2];
