@@ -74,7 +74,7 @@ JNIEXPORT void JNICALL Java_com_twitter_ann_gpu_AnnJni_denseSearch(JNIEnv *env, 
 /* long hnswIndexBuildInsert(int device, int metric, long n, int d, ByteBuffer vectors, ByteBuffer ids, int maxM, int efConstruction,
  *                           long seed, int nThreads)   HnswIndex.insert for every row (TypedHnswIndex.index / Hnsw.append);
  * nThreads >= 1: on that many host threads (1 = the sequential reference graph); nThreads == 0: on the device, deterministic
- * (hnsw_index_build_insert_gpu: 1M x 256 in 3.7 s, 50M in 197 s) */
+ * (hnsw_index_build_insert_gpu: 1M x 256 in 3.7 s, 50M in 149 s) */
 JNIEXPORT jlong JNICALL Java_com_twitter_ann_gpu_AnnJni_hnswIndexBuildInsert(JNIEnv *env, jclass cls, jint device, jint metric, jlong n, jint d,
                                                                              jobject vectors, jobject ids, jint maxM, jint efConstruction,
                                                                              jlong seed, jint nThreads) {
