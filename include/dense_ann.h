@@ -71,6 +71,14 @@ int dann_last_rounds(const dann_index_t *index, int32_t *rounds);
 /* Milliseconds spent in the two GEMM passes and the selection of the last dann_search (HIP events). */
 int dann_last_timing(const dann_index_t *index, float *gemm_a_ms, float *gemm_b_ms, float *select_ms);
 
+/* ComposedQueryable.queryWithDistance (ann/src/main/scala/com/twitter/ann/common/ShardApi.scala:71-87) for batched answers:
+ * every shard (one index per GPU, each over its slice of the vectors) was asked for k_in neighbours per query; concatenate,
+ * order by (distance ascending, id ascending), keep k.  Host arithmetic (the reference merges on the JVM too); exact, because a
+ * distance is not a sum across shards.  Also composes hnsw_search answers.
+ *   ids / dist: [n_shards][nq][k_in], counts: [n_shards][nq]; out_ids / out_dist: [nq][k], out_counts: [nq]. */
+int dann_compose_shards(int32_t n_shards, int32_t nq, int32_t k_in, const int64_t *ids, const float *dist, const int32_t *counts,
+                        int32_t k, int64_t *out_ids, float *out_dist, int32_t *out_counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,7 +88,7 @@ def test_jni_glue_compiles_against_the_minimal_jni_header():
         "simclusters_ann_jni.c": ("com_twitter_simclustersann_gpu_SannJni", ("indexBuild", "indexDestroy", "hostAlloc", "hostFree", "getTweetCandidates0", "heavyRank0", "batcherCreate", "batcherDestroy", "request0")),
         "representation_scorer_jni.c": ("com_twitter_representationscorer_gpu_RsxJni", ("storeBuild", "storeDestroy", "pairScores", "listScores")),
         "ann_jni.c": ("com_twitter_ann_gpu_AnnJni", ("denseIndexBuild", "denseIndexDestroy", "denseSearch", "hnswIndexBuildInsert",
-                                                     "hnswIndexLoadDirectory", "hnswIndexDestroy", "hnswSearch")),
+                                                     "hnswIndexLoadDirectory", "hnswIndexDestroy", "hnswSearch", "composeShards")),
     }
     for fname, (cls, names) in want.items():
         src = os.path.join(jni, fname)

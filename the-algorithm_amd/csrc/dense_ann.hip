@@ -1113,4 +1113,31 @@ int dann_last_timing(const dann_index_t *ix, float *a_ms, float *b_ms, float *se
   return DANN_OK;
 } ABI_CATCH
 
+int dann_compose_shards(int32_t n_shards, int32_t nq, int32_t k_in, const int64_t *ids, const float *dist, const int32_t *counts,
+                        int32_t k, int64_t *out_ids, float *out_dist, int32_t *out_counts) try {
+  if (n_shards < 1 || nq < 0 || k_in < 0 || k < 0) return fail(DANN_EINVAL, "n_shards >= 1, nq / k_in / k >= 0");
+  if (nq > 0 && (!counts || !out_counts || (k_in > 0 && (!ids || !dist)) || (k > 0 && (!out_ids || !out_dist))))
+    return fail(DANN_EINVAL, "NULL argument");
+  std::vector<std::pair<float, int64_t>> all;
+  for (int32_t q = 0; q < nq; ++q) {
+    all.clear();
+    for (int32_t s = 0; s < n_shards; ++s) {
+      const int32_t c = counts[(size_t)s * nq + q];
+      if (c < 0 || c > k_in) return fail(DANN_EINVAL, "a shard's count is outside 0..k_in");
+      const size_t base = ((size_t)s * nq + q) * (size_t)k_in;
+      for (int32_t j = 0; j < c; ++j) all.emplace_back(dist[base + j], ids[base + j]);
+    }
+    std::sort(all.begin(), all.end(), [](const std::pair<float, int64_t> &a, const std::pair<float, int64_t> &b) {
+      return a.first < b.first || (a.first == b.first && a.second < b.second);
+    });
+    const int32_t m = (int32_t)std::min<size_t>(all.size(), (size_t)k);
+    for (int32_t j = 0; j < m; ++j) {
+      out_dist[(size_t)q * k + j] = all[(size_t)j].first;
+      out_ids[(size_t)q * k + j] = all[(size_t)j].second;
+    }
+    out_counts[q] = m;
+  }
+  return DANN_OK;
+} ABI_CATCH
+
 }  // extern "C"

@@ -38,6 +38,8 @@ PROTOS = {
     "dann_search": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dann_last_rounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "dann_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "dann_compose_shards": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
 }
 
 
@@ -153,16 +155,24 @@ class BruteForceIndex:
 
 def compose(shard_results: Sequence[Tuple[np.ndarray, np.ndarray, np.ndarray]], k: int):
     """ComposedQueryable.queryWithDistance (ShardApi.scala:71-87) for batched answers: concatenate every
-    shard's (ids, distances, counts), order by (distance, id), keep k."""
+    shard's (ids, distances, counts), order by (distance, id), keep k -- dann_compose_shards in the library."""
+    lib = _lib()
     nq = shard_results[0][0].shape[0]
+    k_in = max(r[0].shape[1] for r in shard_results)
+
+    def pad(a, dtype):
+        out = np.zeros((nq, k_in), dtype)
+        out[:, :a.shape[1]] = a
+        return out
+
+    s_ids = np.ascontiguousarray(np.stack([pad(r[0], np.int64) for r in shard_results]))
+    s_dist = np.ascontiguousarray(np.stack([pad(r[1], np.float32) for r in shard_results]))
+    s_cnt = np.ascontiguousarray(np.stack([np.asarray(r[2], np.int32) for r in shard_results]))
     ids = np.zeros((nq, k), np.int64)
     dist = np.zeros((nq, k), np.float32)
     cnt = np.zeros(nq, np.int32)
-    for q in range(nq):
-        i = np.concatenate([r[0][q, :r[2][q]] for r in shard_results])
-        d = np.concatenate([r[1][q, :r[2][q]] for r in shard_results])
-        order = np.lexsort((i, d))[:k]
-        cnt[q] = len(order)
-        ids[q, :cnt[q]] = i[order]
-        dist[q, :cnt[q]] = d[order]
+    def ptr(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    _check(lib, lib.dann_compose_shards(len(shard_results), nq, k_in, ptr(s_ids), ptr(s_dist), ptr(s_cnt), k, ptr(ids), ptr(dist), ptr(cnt)))
     return ids, dist, cnt

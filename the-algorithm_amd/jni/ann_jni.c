@@ -142,3 +142,25 @@ JNIEXPORT void JNICALL Java_com_twitter_ann_gpu_AnnJni_hnswSearch(JNIEnv *env, j
                   (int32_t *)BUF(counts)) != HNSW_OK)
     throw_runtime(env, hnsw_last_error());
 }
+
+/* void composeShards(int nShards, int nq, int kIn, ByteBuffer ids /+ long[nShards][nq][kIn] +/, ByteBuffer distances /+ float[..] +/,
+ *                    ByteBuffer counts /+ int[nShards][nq] +/, int k, ByteBuffer outIds, ByteBuffer outDistances, ByteBuffer outCounts)
+ * = ComposedQueryable.queryWithDistance (ShardApi.scala:71-87) over the batched answers of one index per GPU */
+JNIEXPORT void JNICALL Java_com_twitter_ann_gpu_AnnJni_composeShards(JNIEnv *env, jclass cls, jint nShards, jint nq, jint kIn, jobject ids,
+                                                                     jobject distances, jobject counts, jint k, jobject outIds,
+                                                                     jobject outDistances, jobject outCounts) {
+  (void)cls;
+  if (nShards < 1 || nq < 0 || kIn < 0 || k < 0 || !counts || !outCounts || (kIn > 0 && (!ids || !distances)) || (k > 0 && (!outIds || !outDistances))) {
+    throw_runtime(env, "nShards >= 1, nq / kIn / k >= 0 and the direct buffers they need");
+    return;
+  }
+  const jlong rows = (jlong)nShards * nq;
+  if (CAP(counts) / 4 < rows || CAP(outCounts) / 4 < nq || (kIn > 0 && (CAP(ids) / 8 / kIn < rows || CAP(distances) / 4 / kIn < rows)) ||
+      (k > 0 && (CAP(outIds) / 8 / k < nq || CAP(outDistances) / 4 / k < nq))) {
+    throw_runtime(env, "a direct buffer is smaller than nShards x nq x kIn (nq x k) entries");
+    return;
+  }
+  if (dann_compose_shards(nShards, nq, kIn, (const int64_t *)BUF(ids), (const float *)BUF(distances), (const int32_t *)BUF(counts), k,
+                          (int64_t *)BUF(outIds), (float *)BUF(outDistances), (int32_t *)BUF(outCounts)) != DANN_OK)
+    throw_runtime(env, dann_last_error());
+}

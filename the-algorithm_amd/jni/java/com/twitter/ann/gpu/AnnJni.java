@@ -35,6 +35,13 @@ public final class AnnJni {
 
   public static native void hnswIndexDestroy(long index);
 
+  /**
+   * ComposedQueryable.queryWithDistance (ShardApi.scala:71-87) over the batched answers of one index per GPU: ids long[nShards][nq][kIn],
+   * distances float[nShards][nq][kIn], counts int[nShards][nq] in; the k nearest per query, by (distance, id), out.
+   */
+  public static native void composeShards(int nShards, int nq, int kIn, ByteBuffer ids, ByteBuffer distances, ByteBuffer counts, int k,
+                                          ByteBuffer outIds, ByteBuffer outDistances, ByteBuffer outCounts);
+
   /** Hnsw.queryWithDistance for nq queries (HnswParams.ef; Hnsw.scala:125-147). */
   public static native void hnswSearch(long index, int nq, int d, ByteBuffer x, int k, int ef, ByteBuffer distances, ByteBuffer labels,
                                        ByteBuffer counts);
