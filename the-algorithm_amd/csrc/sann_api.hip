@@ -1513,10 +1513,11 @@ extern "C" int sann_debug_call_trace(double *us4, int64_t *calls) {
 // step.  Now ONE thread per index makes every HIP call of this path, and it never waits while it could be submitting:
 //
 //   callers       hand over a job (their argument pointers stay valid: they block until the job is done) and sleep
-//   the engine    for each job: batch_reset + kernels on one of its three streams, the unit kernel chained behind the
-//                 previous job's (as bench.py's replay loop does); up to two jobs run ahead; then, oldest job first:
-//                 finish (wait for ITS kernels, slow tail if flagged) -> copies of the answer enqueued -> the next job is
-//                 submitted while they fly -> wait for the copies -> wake the caller
+//   the engine    for each job: batch_reset + kernels on one of its four streams, the unit kernel chained behind the
+//                 previous job's (as bench.py's replay loop does); up to three jobs run ahead.  Then, in this order: the oldest
+//                 job whose kernels are still out is finished (wait for ITS kernels, slow tail if flagged) and its answer
+//                 sent home by the copy kernel; jobs whose copies have arrived are retired oldest first and their callers
+//                 woken; the engine blocks on a copy only when there is nothing else to do
 //
 // so job i's copies home overlap job i+1's kernels, job i+2's argument pass overlaps both, and nobody contends for the
 // runtime's locks.  SANN_ENGINE=0 restores the per-caller path (kept: it is the simplest statement of the call).
